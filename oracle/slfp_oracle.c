@@ -1,0 +1,279 @@
+/*
+ * slfp_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A plain-C restatement of the reference's SLFP<3,4> / SFP<3,3> fake-quantizers and of
+ * its quantized conv2d forward, used ONLY as the checker by tests/, by
+ * __graft_entry__.smoke() and by bench.py's cpu_baseline leg.  Nothing under
+ * cnns_slfp_quantization_amd/ may import, link or call this file.
+ *
+ * Parity pin: this restatement is checked bit-for-bit against the imported Python
+ * reference (/root/reference/utils/sfp_quant.py) by tests/golden/make_golden.py in the
+ * build container, and against the committed fixtures the .npz files in tests/golden/ everywhere.
+ *
+ * Reference lines restated here:
+ *   quantize_weight(k).forward   utils/sfp_quant.py:10-48
+ *   quantize_act(k).forward      utils/sfp_quant.py:59-97
+ *   Conv2d_Q.forward             utils/conv2d_func.py:20-25   (no bias)
+ *   Conv2d_Q.forward (bias)      utils/conv2d_func.py:41-47
+ *   Linear_Q.forward             utils/conv2d_func.py:60-65
+ *
+ * The reference computes the quantizers with ~25 float32 ATen passes (log2, floor, pow,
+ * round, masked stores).  The result is a pure function of the float32 bit pattern; the
+ * integer form below (thresholds/tables from SURVEY.md section 8a) reproduces it exactly,
+ * including its quirks: one log threshold that is 1 ULP off the mathematically exact
+ * value, the two float32 spellings of the top SLFP code, +-1e-10 for tiny non-zero
+ * inputs, and the linear-then-log double rounding of the activation quantizer.
+ */
+#include <stddef.h>
+#include <stdint.h>
+#include <string.h>
+#include <math.h>
+
+#define SLFP_FMT_ACT8 0 /* quantize_act(8)    sfp_quant.py:80-96 */
+#define SLFP_FMT_W8   1 /* quantize_weight(8) sfp_quant.py:32-47 */
+#define SLFP_FMT_SFP7 2 /* quantize_{act,weight}(7) sfp_quant.py:14-30, 63-78 */
+#define SLFP_FMT_MASK 3
+#define SLFP_FMT_EXT  4 /* extended code points so that decode(encode(x)) == quantize(x) */
+
+/* 2^(k/16) rounded to float32, k = 0..15. */
+static const uint32_t T16[16] = {
+    0x3F800000u, 0x3F85AAC3u, 0x3F8B95C2u, 0x3F91C3D3u, 0x3F9837F0u, 0x3F9EF532u,
+    0x3FA5FED7u, 0x3FAD583Fu, 0x3FB504F3u, 0x3FBD08A4u, 0x3FC5672Au, 0x3FCE248Cu,
+    0x3FD744FDu, 0x3FE0CCDFu, 0x3FEAC0C7u, 0x3FF5257Du};
+
+/* Weight quantizer: mantissa-field thresholds of round(16*log2(m)) (SURVEY 8a table TW). */
+static const uint32_t TW16[16] = {
+    0x02CD87u, 0x08980Fu, 0x0EA43Au, 0x14F4F0u, 0x1B8D3Au, 0x227043u, 0x29A15Bu, 0x3123F6u,
+    0x38FBB0u, 0x412C4Du, 0x49B9BEu, 0x52A81Eu, 0x5BFBB8u, 0x65B907u, 0x6FE4BAu, 0x7A83B3u};
+
+#define BITS_TINY   0x2EDBE6FFu /* float32(1e-10)     sfp_quant.py:43,92 */
+#define BITS_MIN    0x3D800000u /* 0.0625 */
+#define BITS_EIGHTH 0x3E000000u /* 0.125 */
+#define BITS_CLAMP8 0x4175257Au /* float32(15.32165)  sfp_quant.py:46,95 */
+#define BITS_CLAMP7 0x41700000u /* 15.0               sfp_quant.py:29,77 */
+#define BITS_QNAN   0x7FC00000u
+
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+/* Result of quantizing one already-scaled float32. */
+typedef struct {
+    uint32_t value_bits; /* exact float32 bits the reference returns */
+    uint8_t code;        /* canonical code: sign | (E+4) | m */
+    uint8_t ext;         /* extended code (see SLFP_FMT_EXT) */
+} qres_t;
+
+static qres_t quant_one(float q, int fmt) {
+    qres_t r;
+    const uint32_t u = f2u(q);
+    const uint32_t a = u & 0x7FFFFFFFu;
+    const uint32_t sgn = u >> 31;
+    const int bits7 = (fmt == SLFP_FMT_SFP7);
+    const uint32_t sign_code = sgn << (bits7 ? 6 : 7);
+    if (a > 0x7F800000u) { /* NaN: sign(nan)=nan poisons the product (sfp_quant.py:47) */
+        r.value_bits = BITS_QNAN;
+        r.code = r.ext = 0;
+        return r;
+    }
+    if (a == 0) { /* torch.sign(+-0) == 0 -> exact +0 out */
+        r.value_bits = 0;
+        r.code = 0;
+        r.ext = 1; /* spare code point (E+4=0, m=1) = exact zero */
+        return r;
+    }
+    if (a < BITS_MIN) { /* "subnormal": +-1e-10 */
+        r.value_bits = (sgn << 31) | BITS_TINY;
+        r.code = r.ext = (uint8_t)sign_code;
+        return r;
+    }
+    if (a < BITS_EIGHTH) { /* [0.0625, 0.125) -> +-0.125 */
+        r.value_bits = (sgn << 31) | BITS_EIGHTH;
+        r.code = r.ext = (uint8_t)(sign_code | (bits7 ? (1u << 3) : (1u << 4)));
+        return r;
+    }
+    if (bits7) {
+        if (a >= BITS_CLAMP7) {
+            r.value_bits = (sgn << 31) | BITS_CLAMP7;
+            r.code = r.ext = (uint8_t)(sign_code | 0x3Fu);
+            return r;
+        }
+        /* RNE of the mantissa to 3 bits; the carry walks into the exponent field. */
+        const uint32_t idx = (a + 0x7FFFFu + ((a >> 20) & 1u)) >> 20; /* E'<<3 | m */
+        r.value_bits = (sgn << 31) | (idx << 20);                   /* (1+m/8)*2^E exactly */
+        r.code = r.ext = (uint8_t)(sign_code | (idx - (123u << 3)));
+        return r;
+    }
+    if (a > BITS_CLAMP8) { /* clamp literal (second spelling of the top code) */
+        r.value_bits = (sgn << 31) | BITS_CLAMP8;
+        r.code = (uint8_t)(sign_code | 0x7Fu);
+        r.ext = (uint8_t)(sign_code | 0x02u); /* spare code point = clamp literal */
+        return r;
+    }
+    uint32_t idx; /* E'<<4 | m, m in 0..15 */
+    if (fmt == SLFP_FMT_ACT8) {
+        /* linear RNE to 4 bits (sfp_quant.py:88), then the log converter (:89). */
+        const uint32_t lin = (a + 0x3FFFFu + ((a >> 19) & 1u)) >> 19; /* E'<<4 | lin */
+        const uint32_t l = lin & 15u;
+        /* L = [0,1,3,4,...,15,15]: log code 2 is unreachable, 14 and 15 collide. */
+        idx = lin + (l >= 2u) - (l >= 15u);
+    } else {
+        const uint32_t f = a & 0x7FFFFFu;
+        uint32_t m = 0;
+        for (int k = 0; k < 16; ++k) m += (f >= TW16[k]);
+        idx = ((a >> 23) << 4) + m; /* m == 16 carries into the exponent */
+    }
+    const uint32_t m = idx & 15u;
+    const uint32_t e = idx >> 4; /* biased exponent */
+    r.value_bits = (sgn << 31) | (T16[m] + ((e - 127u) << 23));
+    r.code = r.ext = (uint8_t)(sign_code | (idx - (123u << 4)));
+    return r;
+}
+
+static float decode_one(uint8_t code, int fmt) {
+    const int ext = fmt & SLFP_FMT_EXT;
+    const int f = fmt & SLFP_FMT_MASK;
+    if (f == SLFP_FMT_SFP7) {
+        const uint32_t sgn = (code >> 6) & 1u, mag = code & 0x3Fu;
+        if (ext && code == 1) return 0.0f;
+        if (mag == 0) return u2f((sgn << 31) | BITS_TINY);
+        return u2f((sgn << 31) | ((mag + (123u << 3)) << 20));
+    }
+    const uint32_t sgn = code >> 7, mag = code & 0x7Fu;
+    if (ext && code == 1) return 0.0f;
+    if (ext && mag == 2) return u2f((sgn << 31) | BITS_CLAMP8);
+    if (mag == 0) return u2f((sgn << 31) | BITS_TINY);
+    const uint32_t idx = mag + (123u << 4);
+    return u2f((sgn << 31) | (T16[idx & 15u] + (((idx >> 4) - 127u) << 23)));
+}
+
+/* y[i] = Q_fmt(x[i] / scale_div): the value the reference's qfn.forward returns.
+ * The division is a float32 IEEE division (conv2d_func.py:21-22). */
+void slfp_oracle_quantize(const float* x, float* y, size_t n, float scale_div, int fmt) {
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; ++i) {
+        volatile float q = x[i] / scale_div;
+        y[i] = u2f(quant_one(q, fmt & SLFP_FMT_MASK).value_bits);
+    }
+}
+
+void slfp_oracle_encode(const float* x, uint8_t* code, size_t n, float scale_div, int fmt) {
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; ++i) {
+        volatile float q = x[i] / scale_div;
+        qres_t r = quant_one(q, fmt & SLFP_FMT_MASK);
+        code[i] = (fmt & SLFP_FMT_EXT) ? r.ext : r.code;
+    }
+}
+
+void slfp_oracle_decode(const uint8_t* code, float* y, size_t n, int fmt) {
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; ++i) y[i] = decode_one(code[i], fmt);
+}
+
+/*
+ * Conv2d_Q.forward in the reference's own layout (NCHW input, OIHW weight, NCHW output):
+ *   input_q  = QA(x / Ka)                          conv2d_func.py:21
+ *   weight_q = QW(w / Kw)                          conv2d_func.py:22
+ *   bias_q   = bias / Ka / Kw   (if bias)          conv2d_func.py:44
+ *   y        = conv2d(input_q, weight_q, bias_q) * Ka * Kw     conv2d_func.py:23-24
+ * qbits: 8 -> ACT8/W8, 7 -> SFP7 both, 32 -> passthrough (sfp_quant.py:11-12,60-61).
+ * The contraction is accumulated in double and rounded once to float32 (the reference
+ * uses oneDNN float32 with an unspecified summation order; both sit within float32
+ * rounding noise of this value).  The two rescales are sequential float32 roundings.
+ * input_q / weight_q (may be NULL) receive the dequantized operands the reference
+ * stashes on the module.  Returns 0, or -1 on bad arguments.
+ */
+int slfp_oracle_conv2d(const float* x, int64_t N, int64_t C, int64_t H, int64_t W,
+                       const float* w, int64_t O, int64_t KH, int64_t KW, const float* bias,
+                       int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
+                       int groups, float Ka, float Kw, int qbits, float* y, float* input_q,
+                       float* weight_q, float* scratch /* >= N*C*H*W + O*(C/groups)*KH*KW */) {
+    if (groups <= 0 || C % groups || O % groups) return -1;
+    if (qbits != 8 && qbits != 7 && qbits != 32) return -1;
+    const int64_t Cg = C / groups, Og = O / groups;
+    const int64_t Ho = (H + 2 * pad_h - dil_h * (KH - 1) - 1) / stride_h + 1;
+    const int64_t Wo = (W + 2 * pad_w - dil_w * (KW - 1) - 1) / stride_w + 1;
+    if (Ho <= 0 || Wo <= 0) return -1;
+    const size_t nx = (size_t)(N * C * H * W), nw = (size_t)(O * Cg * KH * KW);
+    float* xq = input_q ? input_q : scratch;
+    float* wq = weight_q ? weight_q : scratch + nx;
+    if (qbits == 32) {
+#pragma omp parallel for schedule(static)
+        for (size_t i = 0; i < nx; ++i) { volatile float q = x[i] / Ka; xq[i] = q; }
+        for (size_t i = 0; i < nw; ++i) { volatile float q = w[i] / Kw; wq[i] = q; }
+    } else {
+        slfp_oracle_quantize(x, xq, nx, Ka, qbits == 8 ? SLFP_FMT_ACT8 : SLFP_FMT_SFP7);
+        slfp_oracle_quantize(w, wq, nw, Kw, qbits == 8 ? SLFP_FMT_W8 : SLFP_FMT_SFP7);
+    }
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int64_t n = 0; n < N; ++n) {
+        for (int64_t o = 0; o < O; ++o) {
+            const int64_t g = o / Og;
+            double bq = 0.0;
+            if (bias) {
+                volatile float b1 = bias[o] / Ka;
+                volatile float b2 = b1 / Kw;
+                bq = (double)b2;
+            }
+            for (int64_t ho = 0; ho < Ho; ++ho) {
+                for (int64_t wo = 0; wo < Wo; ++wo) {
+                    double acc = 0.0;
+                    for (int64_t c = 0; c < Cg; ++c) {
+                        const float* xp = xq + ((n * C + g * Cg + c) * H) * W;
+                        const float* wp = wq + ((o * Cg + c) * KH) * KW;
+                        for (int64_t kh = 0; kh < KH; ++kh) {
+                            const int64_t hi = ho * stride_h - pad_h + kh * dil_h;
+                            if (hi < 0 || hi >= H) continue;
+                            for (int64_t kw = 0; kw < KW; ++kw) {
+                                const int64_t wi = wo * stride_w - pad_w + kw * dil_w;
+                                if (wi < 0 || wi >= W) continue;
+                                acc += (double)xp[hi * W + wi] * (double)wp[kh * KW + kw];
+                            }
+                        }
+                    }
+                    volatile float r = (float)(acc + bq);
+                    r = r * Ka;
+                    r = r * Kw;
+                    y[((n * O + o) * Ho + ho) * Wo + wo] = r;
+                }
+            }
+        }
+    }
+    return 0;
+}
+
+/* Linear_Q.forward (conv2d_func.py:60-65): out = linear(QA(x/Ka), QW(w/Kw), b/Kw/Ka)*Kw*Ka.
+ * NOTE the reference divides the bias by Kw first and rescales by Kw first here. */
+int slfp_oracle_linear(const float* x, int64_t B, int64_t I, const float* w, int64_t O,
+                       const float* bias, float Ka, float Kw, int qbits, float* y,
+                       float* scratch /* >= B*I + O*I */) {
+    if (qbits != 8 && qbits != 7 && qbits != 32) return -1;
+    float* xq = scratch;
+    float* wq = scratch + (size_t)(B * I);
+    if (qbits == 32) {
+        for (int64_t i = 0; i < B * I; ++i) { volatile float q = x[i] / Ka; xq[i] = q; }
+        for (int64_t i = 0; i < O * I; ++i) { volatile float q = w[i] / Kw; wq[i] = q; }
+    } else {
+        slfp_oracle_quantize(x, xq, (size_t)(B * I), Ka, qbits == 8 ? SLFP_FMT_ACT8 : SLFP_FMT_SFP7);
+        slfp_oracle_quantize(w, wq, (size_t)(O * I), Kw, qbits == 8 ? SLFP_FMT_W8 : SLFP_FMT_SFP7);
+    }
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int64_t b = 0; b < B; ++b) {
+        for (int64_t o = 0; o < O; ++o) {
+            double acc = 0.0;
+            for (int64_t i = 0; i < I; ++i) acc += (double)xq[b * I + i] * (double)wq[o * I + i];
+            if (bias) {
+                volatile float b1 = bias[o] / Kw;
+                volatile float b2 = b1 / Ka;
+                acc += (double)b2;
+            }
+            volatile float r = (float)acc;
+            r = r * Kw;
+            r = r * Ka;
+            y[b * O + o] = r;
+        }
+    }
+    return 0;
+}
+
+int slfp_oracle_version(void) { return 1; }
