@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of the SLFP<3,4>-quantized conv2d hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W            (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W     (N > 1, one rank per GPU over RCCL)
+
+Workload (BASELINE.json, configs[1]): MobileNetV1 ImageNet 224x224, SLFP<3,4> (Qbits 8),
+batch 256 PER GPU (weak scaling).  One "step" = one batch through ALL 27 Conv2d_Q layers of
+the net -- the hot-path operator utils/conv2d_func.py:20-25 and nothing else --
+each layer reading its own synthetic post-ReLU-like NHWC input that is already resident in
+HBM, through the C ABI (slfp_conv2d_fwd), with weights prepared once (quantize-once cache).
+Layer geometry and the per-layer Ka/Kw come from the reference's own tables
+(cnns_slfp_quantization_amd/data/layer_specs.json).  Random-init weights, synthetic data.
+
+Prints ONE JSON line on rank 0 (see README/DESIGN.md for the field meanings).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from cnns_slfp_quantization_amd import _lib, layer_specs, sharding  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_COPY_GBS = 6290.0       # measured float4-copy ceiling from the same guide
+
+
+class Layer:
+    """One Conv2d_Q layer of the workload, bound to device buffers."""
+
+    def __init__(self, L, spec, batch, dev, passes, gen, rank0_weights=True):
+        self.spec = spec
+        self.batch = batch
+        s = spec
+        self.desc = _lib.ConvDesc(n=batch, c_in=s.c_in, h=s.h, w=s.w, c_out=s.c_out, kh=s.k[0], kw=s.k[1],
+                                  stride_h=s.stride[0], stride_w=s.stride[1], pad_h=s.pad[0], pad_w=s.pad[1],
+                                  dil_h=1, dil_w=1, groups=s.groups, x_layout=_lib.LAYOUT_NHWC,
+                                  y_layout=_lib.LAYOUT_NHWC, qbits=8, ka=float(np.float32(s.Ka)),
+                                  kw_scale=float(np.float32(s.Kw)), mfma_passes=passes, reserved=0)
+        self.kernel = L.slfp_conv2d_kernel_name(ctypes.byref(self.desc)).decode()
+        # synthetic post-ReLU-like activation spanning all 7 binades and both clamps;
+        # the image stem gets a signed N(0,1)-like input
+        x = torch.randn((batch, s.h, s.w, s.c_in), generator=gen, device=dev)
+        x = x if s.c_in == 3 else x.abs_()
+        self.x = x.mul_(4.0 * s.Ka)
+        self.y = torch.empty((batch, s.h_out, s.w_out, s.c_out), device=dev)
+        fan = (s.c_in // s.groups) * s.k[0] * s.k[1]
+        self.w = torch.randn((s.c_out, s.c_in // s.groups, s.k[0], s.k[1]), generator=gen, device=dev)
+        self.w.mul_(min(5.0 * s.Kw, 3.0 * (2.0 / fan) ** 0.5 + 2.0 * s.Kw))
+        self.bias = torch.randn(s.c_out, generator=gen, device=dev) * 0.1 if s.bias else None
+        self.blob = torch.empty(L.slfp_conv2d_wprep_bytes(ctypes.byref(self.desc)), dtype=torch.uint8, device=dev)
+        self.bytes = spec.algorithmic_bytes(batch)
+
+    def prepare(self, L, stream):
+        _lib.check(L.slfp_conv2d_prepare_weights(ctypes.byref(self.desc), self.w.data_ptr(), self.blob.data_ptr(),
+                                                 None, stream))
+
+    def run(self, L, stream):
+        rc = L.slfp_conv2d_fwd(ctypes.byref(self.desc), self.x.data_ptr(), self.blob.data_ptr(),
+                               self.bias.data_ptr() if self.bias is not None else None, self.y.data_ptr(),
+                               None, None, stream)
+        if rc != 0:
+            _lib.check(rc)
+
+
+def cpu_baseline(specs, sample_batch, iters):
+    """The reference's CPU path re-stated with the same ATen op sequence (oracle/torch_port.py,
+    proven bit-identical to the reference in the build container), timed on this box's
+    host cores on a bounded sample of the same workload."""
+    from oracle import torch_port as tp
+    # the GPU box gives one GPU a 16-core CPU share; os.cpu_count() reports the whole host
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(ncpu, 16)))
+    g = torch.Generator().manual_seed(0)
+    data = []
+    for s in specs:
+        x = torch.randn((sample_batch, s.c_in, s.h, s.w), generator=g)
+        x = (x if s.c_in == 3 else x.abs()) * (4.0 * s.Ka)
+        w = torch.randn((s.c_out, s.c_in // s.groups, s.k[0], s.k[1]), generator=g) * (5.0 * s.Kw)
+        b = torch.randn(s.c_out, generator=g) * 0.1 if s.bias else None
+        data.append((s, x, w, b))
+
+    def one_pass():
+        with torch.no_grad():
+            for s, x, w, b in data:
+                tp.conv2d_q(x, w, b, s.stride, s.pad, 1, s.groups, np.float64(s.Ka), np.float64(s.Kw), 8)
+
+    one_pass()  # warm-up
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        one_pass()
+    dt = time.perf_counter() - t0
+    return {"value": round(sample_batch * iters / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"{iters} x batch {sample_batch} through the same {len(specs)} Conv2d_Q layers, "
+                      f"oracle/torch_port.py (the reference's ATen op sequence) on PyTorch-CPU, no_grad"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--net", default="mobilenetv1_imagenet224")
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
+    ap.add_argument("--passes", type=int, default=0, choices=[0, 1, 3], help="pointwise MFMA precision (0 = library default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-batch", type=int, default=16)
+    ap.add_argument("--per-layer", action="store_true", help="also print a per-layer table to stderr")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    L = _lib.load()  # raises if the HIP extension is missing: no fallback
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+
+    specs = layer_specs.conv_layers(args.net)
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    layers = [Layer(L, s, args.batch, dev, args.passes, gen) for s in specs]
+    stream = torch.cuda.current_stream().cuda_stream
+
+    # quantize the weights ONCE on rank 0 and broadcast the prepared blobs as one bucket
+    # (batch-axis sharding: the only collective of the whole path, sharding.py)
+    if rank == 0:
+        for l in layers:
+            l.prepare(L, stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        sharding.broadcast_blobs([l.blob for l in layers], src=0)
+        torch.cuda.synchronize()
+
+    def step():
+        for l in layers:
+            l.run(L, stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- per-kernel timing with HIP events on the launch stream (separate pass) ----
+    ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in layers]
+          for _ in range(args.steps)]
+    for k in range(args.steps):
+        for i, l in enumerate(layers):
+            ev[k][i][0].record()
+            l.run(L, stream)
+            ev[k][i][1].record()
+    torch.cuda.synchronize()
+    layer_ms = [float(np.mean([ev[k][i][0].elapsed_time(ev[k][i][1]) for k in range(args.steps)])) for i in range(len(layers))]
+    fam = {}
+    for l, ms in zip(layers, layer_ms):
+        f = fam.setdefault(l.kernel, {"ms": 0.0, "bytes": 0, "launches": 0})
+        f["ms"] += ms
+        f["bytes"] += l.bytes
+        f["launches"] += 1
+    dominant = max(fam, key=lambda k: fam[k]["ms"])
+    dom = fam[dominant]
+    dom_gbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+
+    if rank == 0:
+        imgs = args.batch * world * args.steps
+        value = imgs / dt
+        bytes_img = layer_specs.algorithmic_bytes_per_image(args.net, args.batch)
+        whole_gbs = bytes_img * value / 1e9 / world  # per GPU
+        out = {
+            "metric": "images/sec at batch 256, MobileNetV1 SLFP<3,4> ImageNet-224; % HBM roofline",
+            "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32 (1x1 contraction: fp16 MFMA operands, f32 accumulate)", "data": "synthetic",
+            "config": {"workload": f"{args.net}: all {len(layers)} Conv2d_Q layers, SLFP<3,4> Qbits=8, NHWC, "
+                                   f"batch {args.batch} per GPU, inputs resident in HBM",
+                       "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                       "parallelism": f"batch-sharded x{world}, one-time RCCL weight broadcast",
+                       "pointwise_mfma": next((l.kernel for l in layers if l.kernel.startswith("pw_")), None)},
+            "hbm_roofline_frac_whole_path": round(whole_gbs / HBM_PEAK_GBS, 4),
+            "algorithmic_bytes_per_image": int(bytes_img),
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(dom_gbs, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(dom_gbs / HBM_PEAK_GBS, 4),
+                         "frac_of_measured_copy_ceiling": round(dom_gbs / HBM_COPY_GBS, 4), "traffic": None,
+                         "launches_per_step": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
+                         "algorithmic_bytes_per_launch": int(dom["bytes"] / dom["launches"])},
+            "kernels": {k: {"ms_per_step": round(v["ms"], 4), "GB/s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
+                            "launches": v["launches"]} for k, v in fam.items()},
+        }
+        if args.per_layer:
+            for l, ms in zip(layers, layer_ms):
+                s = l.spec
+                print(f"  {l.kernel:18s} {s.c_in:4d}->{s.c_out:4d} k{s.k[0]} s{s.stride[0]} {s.h:3d}->{s.h_out:3d}  "
+                      f"{ms:8.4f} ms  {l.bytes / ms / 1e6:8.1f} GB/s", file=sys.stderr)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(specs, args.cpu_sample_batch, 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

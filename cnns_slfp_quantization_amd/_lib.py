@@ -1,0 +1,102 @@
+"""ctypes binding of libslfp_hip.so (include/slfp.h).  No torch types cross this boundary:
+device pointers are passed as integers, the stream as the raw hipStream_t handle.
+
+There is NO fallback: if the library is missing or a call fails this raises.  The CPU
+checker lives in oracle/ and is never imported from here.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libslfp_hip.so")
+
+OK, ERR_BAD_ARG, ERR_SHAPE, ERR_UNSUPPORTED, ERR_ALIGNMENT, ERR_HIP = 0, -1, -2, -3, -4, -5
+FMT_ACT8, FMT_W8, FMT_SFP7, FMT_EXT = 0, 1, 2, 4
+LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
+MFMA_DEFAULT, MFMA_F16X1, MFMA_F16X3 = 0, 1, 3
+
+# every symbol include/slfp.h declares (tests check the .so exports exactly these)
+SYMBOLS = (
+    "slfp_version", "slfp_last_error", "slfp_device_count",
+    "slfp_encode_f32", "slfp_decode_f32", "slfp_quantize_f32",
+    "slfp_conv2d_out_shape", "slfp_conv2d_kernel_name", "slfp_conv2d_wprep_bytes",
+    "slfp_conv2d_prepare_weights", "slfp_conv2d_workspace_bytes", "slfp_conv2d_fwd",
+    "slfp_linear_workspace_bytes", "slfp_linear_fwd",
+    "slfp_nchw_to_nhwc_f32", "slfp_nhwc_to_nchw_f32",
+)
+
+
+class ConvDesc(ctypes.Structure):
+    """struct slfp_conv2d_desc"""
+    _fields_ = [
+        ("n", ctypes.c_int64), ("c_in", ctypes.c_int64), ("h", ctypes.c_int64), ("w", ctypes.c_int64),
+        ("c_out", ctypes.c_int64), ("kh", ctypes.c_int64), ("kw", ctypes.c_int64),
+        ("stride_h", ctypes.c_int32), ("stride_w", ctypes.c_int32), ("pad_h", ctypes.c_int32),
+        ("pad_w", ctypes.c_int32), ("dil_h", ctypes.c_int32), ("dil_w", ctypes.c_int32),
+        ("groups", ctypes.c_int32), ("x_layout", ctypes.c_int32), ("y_layout", ctypes.c_int32),
+        ("qbits", ctypes.c_int32), ("ka", ctypes.c_float), ("kw_scale", ctypes.c_float),
+        ("mfma_passes", ctypes.c_int32), ("reserved", ctypes.c_int32),
+    ]
+
+
+class SlfpError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__(f"libslfp_hip: {text} (status {code})")
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Load libslfp_hip.so; raises RuntimeError (never falls back) if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the SLFP HIP extension is not built. "
+            "Run `python -m cnns_slfp_quantization_amd.build` (needs hipcc). There is no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, sz, ci, cf, i64 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_float, ctypes.c_int64
+    dp = ctypes.POINTER(ConvDesc)
+    sigs = {
+        "slfp_version": (ci, []),
+        "slfp_last_error": (ctypes.c_char_p, []),
+        "slfp_device_count": (ci, []),
+        "slfp_encode_f32": (ci, [vp, vp, sz, cf, ci, vp]),
+        "slfp_decode_f32": (ci, [vp, vp, sz, ci, vp]),
+        "slfp_quantize_f32": (ci, [vp, vp, sz, cf, ci, vp]),
+        "slfp_conv2d_out_shape": (ci, [dp, ctypes.POINTER(i64), ctypes.POINTER(i64)]),
+        "slfp_conv2d_kernel_name": (ctypes.c_char_p, [dp]),
+        "slfp_conv2d_wprep_bytes": (sz, [dp]),
+        "slfp_conv2d_prepare_weights": (ci, [dp, vp, vp, vp, vp]),
+        "slfp_conv2d_workspace_bytes": (sz, [dp]),
+        "slfp_conv2d_fwd": (ci, [dp, vp, vp, vp, vp, vp, vp, vp]),
+        "slfp_linear_workspace_bytes": (sz, [i64, i64, i64]),
+        "slfp_linear_fwd": (ci, [vp, vp, vp, vp, i64, i64, i64, cf, cf, ci, ci, vp, vp]),
+        "slfp_nchw_to_nhwc_f32": (ci, [vp, vp, i64, i64, i64, i64, vp]),
+        "slfp_nhwc_to_nchw_f32": (ci, [vp, vp, i64, i64, i64, i64, vp]),
+    }
+    assert set(sigs) == set(SYMBOLS)
+    for name, (res, args) in sigs.items():
+        fn = getattr(L, name)  # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def last_error():
+    return load().slfp_last_error().decode("utf-8", "replace")
+
+
+def check(rc):
+    """Map a C status to the exception the reference's Python would raise."""
+    if rc == OK:
+        return
+    text = last_error()
+    if rc in (ERR_BAD_ARG, ERR_SHAPE):
+        # the reference surfaces these from F.conv2d / asserts as RuntimeError/AssertionError
+        raise SlfpError(rc, text)
+    raise SlfpError(rc, text)

@@ -1,0 +1,342 @@
+"""Host-side mirror of the reference's utils/conv2d_func.py on top of the HIP C ABI.
+
+Drop-in operator API (same names, positional order, attributes and state-dict keys):
+
+    conv2d_Q(q_bit, Kw, Ka)       -> class Conv2d_Q(nn.Conv2d)   utils/conv2d_func.py:8-26
+    conv2d_Q_bias(q_bit, Kw, Ka)  -> class Conv2d_Q(nn.Conv2d)   utils/conv2d_func.py:28-48
+    linear_Q(q_bit, Kw, Ka)       -> class Linear_Q(nn.Linear)   utils/conv2d_func.py:50-66
+
+Where the reference runs  x/Ka -> ~25-pass quantize_act -> w/Kw -> ~25-pass
+quantize_weight (every forward) -> fp32 F.conv2d -> *Ka*Kw  (conv2d_func.py:20-25), this
+module makes ONE call into libslfp_hip.so (slfp_conv2d_fwd): the SLFP encode is applied
+inline on the kernels' load path, weights are quantized once per weight version into a
+kernel-specific blob (cache invalidated exactly on `weight._version` / storage change),
+and `input_q` / `weight_q` -- which the CIFAR nets read back after every forward
+(nets_cifar/mobilenetv1.py:88-171) -- are materialised lazily on first access.
+
+Memory layout: the kernels are NHWC.  A `torch.channels_last` input is consumed and
+produced in place (zero copies; BN/ReLU keep the format); an NCHW-contiguous input is
+transposed inside the C ABI and, by default, the output comes back NCHW so that code
+which `.view()`s NCHW strides (nets_cifar/shufflenet_v2.py:41) keeps working.  Use
+`model.to(memory_format=torch.channels_last)` + a channels_last input for the fast path.
+
+There is no CPU compute path here (q_bit 8/7 need a ROCm tensor; q_bit 32 is the
+reference's passthrough).  Autograd: forward is always the HIP kernel; backward is the
+reference's STE composite on the GPU (training is outside the accelerated scope).
+"""
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+from .sfp_quant import *  # noqa: F401,F403  (the reference re-exports these: conv2d_func.py:5)
+from .sfp_quant import _require_gpu_f32, _stream_handle, hip_quantize, weight_quantize_func, act_quantize_func
+
+__all__ = ["torch", "nn", "F", "np", "conv2d_Q", "conv2d_Q_bias", "linear_Q", "options",
+           "quantize_weight", "quantize_act", "quantize_layerout",
+           "weight_quantize_func", "act_quantize_func", "layerout_quantize_func"]
+
+
+class _Options:
+    """Process-wide knobs of the HIP path (not part of the reference API)."""
+    mfma_passes = _lib.MFMA_DEFAULT  # pointwise MFMA operand precision, see include/slfp.h
+    output_layout = "same"           # "same": follow the input's memory format; "nhwc": always channels_last
+    eager_stash = False              # True: materialise input_q / weight_q on every forward like the reference
+
+
+options = _Options()
+
+
+def _f32(v):
+    """float32(K) as a Python float: the cast ATen applies to the 0-dim float64 scale."""
+    return float(np.float32(float(v)))
+
+
+def _scalar_scale(t, name):
+    if t.numel() != 1:
+        raise ValueError(f"{name} must be a scalar calibration scale, got a tensor of shape {tuple(t.shape)} "
+                         "(pass the per-layer value, as the reference nets do)")
+    v = float(t)
+    if not v > 0:
+        raise ValueError(f"{name} must be > 0, got {v}")
+    return v
+
+
+def _pair(v):
+    return (int(v[0]), int(v[1])) if isinstance(v, (tuple, list)) else (int(v), int(v))
+
+
+class _PreparedWeights:
+    """Per-module cache of the kernel-specific weight blob (and the OIHW weight_q tensor)."""
+
+    def __init__(self):
+        self.key = None
+        self.blob = None
+        self.weight_q = None
+
+    def get(self, L, desc, weight, want_weight_q):
+        key = (weight.device, weight.data_ptr(), weight._version, tuple(weight.shape), desc.qbits,
+               desc.kw_scale, L.slfp_conv2d_kernel_name(ctypes.byref(desc)))
+        if key != self.key or self.blob is None or (want_weight_q and self.weight_q is None):
+            nbytes = L.slfp_conv2d_wprep_bytes(ctypes.byref(desc))
+            w = weight.detach()
+            w = w if w.is_contiguous() else w.contiguous()  # OIHW
+            blob = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+            wq = torch.empty_like(w) if want_weight_q else None
+            _lib.check(L.slfp_conv2d_prepare_weights(ctypes.byref(desc), w.data_ptr(), blob.data_ptr(),
+                                                     wq.data_ptr() if wq is not None else None,
+                                                     _stream_handle(weight)))
+            self.key, self.blob, self.weight_q = key, blob, wq
+        return self.blob
+
+
+def _hip_conv2d(mod, x, weight, bias):
+    """One slfp_conv2d_fwd call for module `mod` (an nn.Conv2d subclass below)."""
+    _require_gpu_f32(x, "Conv2d_Q")
+    if weight.device != x.device:
+        raise RuntimeError(f"Conv2d_Q: input is on {x.device} but weight is on {weight.device}")
+    squeeze = x.dim() == 3
+    if squeeze:
+        x = x.unsqueeze(0)
+    if x.dim() != 4:
+        raise RuntimeError(f"Expected 3D (unbatched) or 4D (batched) input to conv2d, but got input of size: {list(x.shape)}")
+    if isinstance(mod.padding, str) or mod.padding_mode != "zeros":
+        raise NotImplementedError("Conv2d_Q (HIP): only explicit zero padding is supported")
+    L = _lib.load()
+    nhwc_in = x.is_contiguous(memory_format=torch.channels_last)
+    if not nhwc_in and not x.is_contiguous():
+        x = x.contiguous()
+    N, C, H, W = x.shape
+    if C != mod.in_channels:
+        raise RuntimeError(f"Given groups={mod.groups}, weight of size {list(weight.shape)}, expected input"
+                           f"{list(x.shape)} to have {mod.in_channels} channels, but got {C} channels instead")
+    sh, sw = _pair(mod.stride)
+    ph, pw = _pair(mod.padding)
+    dh, dw = _pair(mod.dilation)
+    nhwc_out = nhwc_in or options.output_layout == "nhwc"
+    d = _lib.ConvDesc(n=N, c_in=C, h=H, w=W, c_out=mod.out_channels, kh=weight.shape[2], kw=weight.shape[3],
+                      stride_h=sh, stride_w=sw, pad_h=ph, pad_w=pw, dil_h=dh, dil_w=dw, groups=mod.groups,
+                      x_layout=_lib.LAYOUT_NHWC if nhwc_in else _lib.LAYOUT_NCHW,
+                      y_layout=_lib.LAYOUT_NHWC if nhwc_out else _lib.LAYOUT_NCHW,
+                      qbits=mod.q_bit, ka=_f32(_scalar_scale(mod.Ka, "Ka")), kw_scale=_f32(_scalar_scale(mod.Kw, "Kw")),
+                      mfma_passes=options.mfma_passes, reserved=0)
+    ho, wo = ctypes.c_int64(), ctypes.c_int64()
+    with torch.cuda.device(x.device):
+        _lib.check(L.slfp_conv2d_out_shape(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)))
+        blob = mod._prep.get(L, d, weight, want_weight_q=options.eager_stash)
+        y = torch.empty((N, mod.out_channels, ho.value, wo.value), dtype=torch.float32, device=x.device,
+                        memory_format=torch.channels_last if nhwc_out else torch.contiguous_format)
+        ws_bytes = L.slfp_conv2d_workspace_bytes(ctypes.byref(d))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None
+        b = None
+        if bias is not None:
+            b = bias.detach()
+            b = b if b.is_contiguous() else b.contiguous()
+        xq = torch.empty_like(x) if options.eager_stash else None
+        _lib.check(L.slfp_conv2d_fwd(ctypes.byref(d), x.data_ptr(), blob.data_ptr(),
+                                     b.data_ptr() if b is not None else None, y.data_ptr(),
+                                     xq.data_ptr() if xq is not None else None,
+                                     ws.data_ptr() if ws is not None else None, _stream_handle(x)))
+    mod._last_kernel = L.slfp_conv2d_kernel_name(ctypes.byref(d)).decode()
+    mod._last_input = x.detach()
+    mod._input_q = xq
+    return y.squeeze(0) if squeeze else y
+
+
+class _SlfpConv2dFn(torch.autograd.Function):
+    """HIP forward; backward = the reference's composite (STE through both quantizers:
+    utils/sfp_quant.py:50-53, :99-102; conv gradients from torch.nn.grad on the GPU)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, mod, scaled_bias):
+        ctx.mod = mod
+        ctx.scaled_bias = scaled_bias
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return _hip_conv2d(mod, x, weight, bias if scaled_bias else None)
+
+    @staticmethod
+    def backward(ctx, gy):
+        mod = ctx.mod
+        x, weight = ctx.saved_tensors
+        ka, kw = _f32(mod.Ka), _f32(mod.Kw)
+        fa = _lib.FMT_ACT8 if mod.q_bit == 8 else _lib.FMT_SFP7
+        fw = _lib.FMT_W8 if mod.q_bit == 8 else _lib.FMT_SFP7
+        g = (gy * kw * ka).contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            wq = hip_quantize(weight.detach().contiguous(), kw, fw)
+            gx = torch.nn.grad.conv2d_input(x.shape, wq, g, mod.stride, mod.padding, mod.dilation, mod.groups) / ka
+        if ctx.needs_input_grad[1]:
+            xq = hip_quantize(x.detach().contiguous(), ka, fa)
+            gw = torch.nn.grad.conv2d_weight(xq, weight.shape, g, mod.stride, mod.padding, mod.dilation, mod.groups) / kw
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gy.sum(dim=(0, 2, 3)) if ctx.scaled_bias else g.sum(dim=(0, 2, 3))
+        return gx, gw, gb, None, None
+
+
+def _conv_class(q_bit, Kw, Ka, bias_default, scaled_bias):
+    class Conv2d_Q(nn.Conv2d):
+        # Kw, Ka are positional arguments 4 and 5 (utils/conv2d_func.py:10-11, :30)
+        def __init__(self, in_channels, out_channels, kernel_size, Kw=Kw, Ka=Ka,
+                     stride=1, padding=0, dilation=1, groups=1, bias=bias_default):
+            super(Conv2d_Q, self).__init__(in_channels, out_channels, kernel_size, stride,
+                                           padding, dilation, groups, bias)
+            self.q_bit = q_bit
+            self.quantize_weight = weight_quantize_func(q_bit=q_bit)
+            self.quantize_act = act_quantize_func(q_bit=q_bit)
+            # plain attributes, 0-dim float64, stay on the CPU (utils/conv2d_func.py:17-18)
+            self.Kw = torch.tensor(Kw)
+            self.Ka = torch.tensor(Ka)
+            self._prep = _PreparedWeights()
+            self._last_input = None
+            self._input_q = None
+            self._weight_q32 = None
+            self._last_kernel = None
+            self.output = None
+
+        # -- the reference stores these on every forward (utils/conv2d_func.py:21-22);
+        #    here they are computed on first access after a forward.
+        @property
+        def input_q(self):
+            if self.q_bit == 32:
+                return self._input_q
+            if self._input_q is None and self._last_input is not None:
+                fmt = _lib.FMT_ACT8 if self.q_bit == 8 else _lib.FMT_SFP7
+                self._input_q = hip_quantize(self._last_input, _f32(self.Ka), fmt)
+            return self._input_q
+
+        @property
+        def weight_q(self):
+            if self.q_bit == 32:
+                return self._weight_q32
+            if self._last_input is None:
+                return None
+            if self._prep.weight_q is None or self._prep.key is None or self._prep.key[2] != self.weight._version:
+                fmt = _lib.FMT_W8 if self.q_bit == 8 else _lib.FMT_SFP7
+                self._prep.weight_q = hip_quantize(self.weight.detach().contiguous(), _f32(self.Kw), fmt)
+            return self._prep.weight_q
+
+        def forward(self, input, order=None):
+            if self.q_bit == 32:
+                # identity quantizers (utils/sfp_quant.py:11-12, :60-61): stock ATen, any device
+                self._input_q = input / self.Ka
+                self._weight_q32 = self.weight / self.Kw
+                b = self.bias
+                if b is not None and scaled_bias:
+                    b = b / self.Ka / self.Kw
+                self.output = F.conv2d(self._input_q, self._weight_q32, b, self.stride, self.padding,
+                                       self.dilation, self.groups) * self.Ka * self.Kw
+                return self.output
+            if self.q_bit not in (8, 7):
+                raise UnboundLocalError("q_bit must be 32, 8 or 7 (utils/sfp_quant.py:142-147)")
+            need_grad = torch.is_grad_enabled() and (input.requires_grad or self.weight.requires_grad or
+                                                     (self.bias is not None and self.bias.requires_grad))
+            if need_grad:
+                out = _SlfpConv2dFn.apply(input, self.weight, self.bias, self, scaled_bias)
+            else:
+                out = _hip_conv2d(self, input, self.weight, self.bias if scaled_bias else None)
+            if self.bias is not None and not scaled_bias:
+                # conv2d_Q hands the raw bias to F.conv2d (utils/conv2d_func.py:23): (conv + b)*Ka*Kw
+                out = out + (self.bias * self.Ka * self.Kw).to(out.dtype).view(1, -1, 1, 1)
+            self.output = out
+            return out
+
+    return Conv2d_Q
+
+
+def conv2d_Q(q_bit, Kw, Ka):
+    """utils/conv2d_func.py:8-26: bias defaults to False and is NOT rescaled."""
+    return _conv_class(q_bit, Kw, Ka, bias_default=False, scaled_bias=False)
+
+
+def conv2d_Q_bias(q_bit, Kw, Ka):
+    """utils/conv2d_func.py:28-48: bias defaults to True, bias_q = bias / Ka / Kw."""
+    return _conv_class(q_bit, Kw, Ka, bias_default=True, scaled_bias=True)
+
+
+def _hip_linear(mod, x, weight, bias):
+    _require_gpu_f32(x, "Linear_Q")
+    L = _lib.load()
+    lead = x.shape[:-1]
+    x2 = x.reshape(-1, x.shape[-1])
+    x2 = x2 if x2.is_contiguous() else x2.contiguous()
+    B, I = x2.shape
+    O = weight.shape[0]
+    if I != weight.shape[1]:
+        raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({B}x{I} and {weight.shape[1]}x{O})")
+    w = weight.detach()
+    w = w if w.is_contiguous() else w.contiguous()
+    b = None
+    if bias is not None:
+        b = bias.detach()
+        b = b if b.is_contiguous() else b.contiguous()
+    y = torch.empty((B, O), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        ws = torch.empty(max(L.slfp_linear_workspace_bytes(B, I, O), 16), dtype=torch.uint8, device=x.device)
+        _lib.check(L.slfp_linear_fwd(x2.data_ptr(), w.data_ptr(), b.data_ptr() if b is not None else None,
+                                     y.data_ptr(), B, I, O, _f32(_scalar_scale(mod.Ka, "Ka")),
+                                     _f32(_scalar_scale(mod.Kw, "Kw")), mod.q_bit, options.mfma_passes,
+                                     ws.data_ptr(), _stream_handle(x)))
+    return y.reshape(*lead, O)
+
+
+class _SlfpLinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, mod):
+        ctx.mod = mod
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return _hip_linear(mod, x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, gy):
+        mod = ctx.mod
+        x, weight = ctx.saved_tensors
+        ka, kw = _f32(mod.Ka), _f32(mod.Kw)
+        fa = _lib.FMT_ACT8 if mod.q_bit == 8 else _lib.FMT_SFP7
+        fw = _lib.FMT_W8 if mod.q_bit == 8 else _lib.FMT_SFP7
+        g = gy * kw * ka
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = (g @ hip_quantize(weight.detach().contiguous(), kw, fw)) / ka
+        if ctx.needs_input_grad[1]:
+            xq = hip_quantize(x.detach().contiguous(), ka, fa)
+            gw = (g.reshape(-1, g.shape[-1]).t() @ xq.reshape(-1, xq.shape[-1])) / kw
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gy.reshape(-1, gy.shape[-1]).sum(0)
+        return gx, gw, gb, None
+
+
+def linear_Q(q_bit, Kw, Ka):
+    """utils/conv2d_func.py:50-66 (next-row component: same C ABI, pointwise kernel family)."""
+    class Linear_Q(nn.Linear):
+        def __init__(self, in_features, out_features, Kw=Kw, Ka=Ka, bias=True):
+            super(Linear_Q, self).__init__(in_features, out_features, bias)
+            self.q_bit = q_bit
+            self.quantize_weight = weight_quantize_func(q_bit=q_bit)
+            self.quantize_act = act_quantize_func(q_bit=q_bit)
+            self.Kw = torch.tensor(Kw)
+            self.Ka = torch.tensor(Ka)
+
+        def forward(self, input):
+            if self.q_bit == 32:
+                self.input_q = input / self.Ka
+                self.weight_q = self.weight / self.Kw
+                # the reference dereferences self.bias unconditionally (utils/conv2d_func.py:63)
+                self.bias_q = self.bias / self.Kw / self.Ka
+                return F.linear(self.input_q, self.weight_q, self.bias_q) * self.Kw * self.Ka
+            if self.q_bit not in (8, 7):
+                raise UnboundLocalError("q_bit must be 32, 8 or 7 (utils/sfp_quant.py:142-147)")
+            if self.bias is None:
+                raise TypeError("unsupported operand type(s) for /: 'NoneType' and 'Tensor'")  # as the reference
+            need_grad = torch.is_grad_enabled() and (input.requires_grad or self.weight.requires_grad or
+                                                     self.bias.requires_grad)
+            if need_grad:
+                return _SlfpLinearFn.apply(input, self.weight, self.bias, self)
+            return _hip_linear(self, input, self.weight, self.bias)
+
+    return Linear_Q

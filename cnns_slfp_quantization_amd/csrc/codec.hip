@@ -1,0 +1,201 @@
+// codec.hip -- elementwise SLFP/SFP codec kernels + NCHW<->NHWC transposes (gfx950).
+//
+// Replaces the reference's ~25-pass ATen fake-quantizers (utils/sfp_quant.py:10-48,
+// :59-97) by ONE HBM-bound pass: 16-byte loads, integer encode, 16-byte (or 4-byte code)
+// stores.  Roofline: 8 B/element (quantize) or 5 B/element (encode) of HBM traffic.
+#include <cstdarg>
+#include <cstdio>
+#include "slfp_device.hpp"
+#include "slfp_host.hpp"
+
+namespace slfp {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SLFP_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+    return SLFP_OK;
+}
+
+const char* last_error_text() { return g_err; }
+
+constexpr int kThreads = 256;
+
+// MODE 0: y = Q(x/scale) float32; MODE 1: code byte.
+template <int FMT, int MODE>
+__global__ __launch_bounds__(kThreads) void k_codec(const float* __restrict__ x, void* __restrict__ out,
+                                                    size_t n, float scale, int ext, int vec_ok) {
+    __shared__ uint32_t sT[16];
+    lut_fill(sT);
+    __syncthreads();
+    const size_t nvec = vec_ok ? n / 4 : 0;
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += stride) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        const uint32_t u0 = __float_as_uint(v.x / scale), u1 = __float_as_uint(v.y / scale);
+        const uint32_t u2 = __float_as_uint(v.z / scale), u3 = __float_as_uint(v.w / scale);
+        if constexpr (MODE == 0) {
+            float4 r;
+            r.x = __uint_as_float(quant_bits<FMT>(u0, sT));
+            r.y = __uint_as_float(quant_bits<FMT>(u1, sT));
+            r.z = __uint_as_float(quant_bits<FMT>(u2, sT));
+            r.w = __uint_as_float(quant_bits<FMT>(u3, sT));
+            reinterpret_cast<float4*>(out)[i] = r;
+        } else {
+            const uint32_t c = quant_code<FMT>(u0, ext) | (quant_code<FMT>(u1, ext) << 8) |
+                               (quant_code<FMT>(u2, ext) << 16) | (quant_code<FMT>(u3, ext) << 24);
+            reinterpret_cast<uint32_t*>(out)[i] = c;
+        }
+    }
+    // scalar tail (and the whole array when a pointer is not 16-byte aligned)
+    for (size_t i = nvec * 4 + (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+        const uint32_t u = __float_as_uint(x[i] / scale);
+        if constexpr (MODE == 0) {
+            reinterpret_cast<float*>(out)[i] = __uint_as_float(quant_bits<FMT>(u, sT));
+        } else {
+            reinterpret_cast<uint8_t*>(out)[i] = (uint8_t)quant_code<FMT>(u, ext);
+        }
+    }
+}
+
+template <int FMT>
+__global__ __launch_bounds__(kThreads) void k_decode(const uint8_t* __restrict__ code, float* __restrict__ y,
+                                                     size_t n, int ext, int vec_ok) {
+    __shared__ uint32_t sT[16];
+    lut_fill(sT);
+    __syncthreads();
+    const size_t nvec = vec_ok ? n / 4 : 0;
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += stride) {
+        const uint32_t c = reinterpret_cast<const uint32_t*>(code)[i];
+        float4 r;
+        r.x = __uint_as_float(decode_bits<FMT>(c & 0xFFu, ext, sT));
+        r.y = __uint_as_float(decode_bits<FMT>((c >> 8) & 0xFFu, ext, sT));
+        r.z = __uint_as_float(decode_bits<FMT>((c >> 16) & 0xFFu, ext, sT));
+        r.w = __uint_as_float(decode_bits<FMT>(c >> 24, ext, sT));
+        reinterpret_cast<float4*>(y)[i] = r;
+    }
+    for (size_t i = nvec * 4 + (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride)
+        y[i] = __uint_as_float(decode_bits<FMT>(code[i], ext, sT));
+}
+
+static int grid_for(size_t n) {
+    size_t blocks = (n / 4 + kThreads - 1) / kThreads;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 256 * 8) blocks = 256 * 8;  // 8 blocks per CU, grid-stride the rest
+    return (int)blocks;
+}
+
+template <int MODE>
+static int launch_codec(const float* x, void* out, size_t n, float scale, int fmt, hipStream_t st) {
+    const int f = fmt & kFmtMask, ext = (fmt & kFmtExt) ? 1 : 0;
+    const int vec_ok = aligned16(x) && ((reinterpret_cast<uintptr_t>(out) & (MODE == 0 ? 15u : 3u)) == 0);
+    const int g = grid_for(n);
+    switch (f) {
+        case kFmtAct8: hipLaunchKernelGGL((k_codec<kFmtAct8, MODE>), dim3(g), dim3(kThreads), 0, st, x, out, n, scale, ext, vec_ok); break;
+        case kFmtW8: hipLaunchKernelGGL((k_codec<kFmtW8, MODE>), dim3(g), dim3(kThreads), 0, st, x, out, n, scale, ext, vec_ok); break;
+        case kFmtSfp7: hipLaunchKernelGGL((k_codec<kFmtSfp7, MODE>), dim3(g), dim3(kThreads), 0, st, x, out, n, scale, ext, vec_ok); break;
+        default: return fail(SLFP_ERR_BAD_ARG, "unknown codec format %d", fmt);
+    }
+    return check_launch("slfp codec kernel");
+}
+
+int launch_quantize(const float* x, float* y, size_t n, float scale, int fmt, hipStream_t st) {
+    return launch_codec<0>(x, y, n, scale, fmt, st);
+}
+
+// ---- NCHW <-> NHWC: per image a [R][Cc] -> [Cc][R] transpose through a padded LDS tile ----
+__global__ __launch_bounds__(256) void k_transpose(const float* __restrict__ x, float* __restrict__ y,
+                                                   int64_t rows, int64_t cols) {
+    __shared__ float tile[32][33];
+    const int64_t img = blockIdx.z;
+    const float* xi = x + img * rows * cols;
+    float* yi = y + img * rows * cols;
+    const int64_t c0 = (int64_t)blockIdx.x * 32, r0 = (int64_t)blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int j = ty; j < 32; j += 8) {
+        const int64_t r = r0 + j, c = c0 + tx;
+        if (r < rows && c < cols) tile[j][tx] = xi[r * cols + c];
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int64_t c = c0 + j, r = r0 + tx;
+        if (r < rows && c < cols) yi[c * rows + r] = tile[tx][j];
+    }
+}
+
+static int launch_transpose(const float* x, float* y, int64_t n, int64_t rows, int64_t cols, hipStream_t st) {
+    if (!x || !y || n <= 0 || rows <= 0 || cols <= 0) return fail(SLFP_ERR_BAD_ARG, "transpose: bad argument");
+    if (n > 65535 || ceil_div(rows, 32) > 65535) return fail(SLFP_ERR_UNSUPPORTED, "transpose: grid too large");
+    dim3 grid((unsigned)ceil_div(cols, 32), (unsigned)ceil_div(rows, 32), (unsigned)n);
+    hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, st, x, y, rows, cols);
+    return check_launch("slfp transpose kernel");
+}
+
+}  // namespace slfp
+
+using namespace slfp;
+
+extern "C" {
+
+int slfp_version(void) { return SLFP_ABI_VERSION; }
+const char* slfp_last_error(void) { return last_error_text(); }
+
+int slfp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+int slfp_encode_f32(const float* x, uint8_t* code, size_t n, float scale_div, int fmt, void* stream) {
+    if (n == 0) return SLFP_OK;
+    if (!x || !code) return fail(SLFP_ERR_BAD_ARG, "slfp_encode_f32: null pointer");
+    if (!(scale_div > 0.f)) return fail(SLFP_ERR_BAD_ARG, "slfp_encode_f32: scale must be > 0");
+    return launch_codec<1>(x, code, n, scale_div, fmt, as_stream(stream));
+}
+
+int slfp_quantize_f32(const float* x, float* y, size_t n, float scale_div, int fmt, void* stream) {
+    if (n == 0) return SLFP_OK;
+    if (!x || !y) return fail(SLFP_ERR_BAD_ARG, "slfp_quantize_f32: null pointer");
+    if (!(scale_div > 0.f)) return fail(SLFP_ERR_BAD_ARG, "slfp_quantize_f32: scale must be > 0");
+    return launch_codec<0>(x, y, n, scale_div, fmt, as_stream(stream));
+}
+
+int slfp_decode_f32(const uint8_t* code, float* y, size_t n, int fmt, void* stream) {
+    if (n == 0) return SLFP_OK;
+    if (!code || !y) return fail(SLFP_ERR_BAD_ARG, "slfp_decode_f32: null pointer");
+    const int f = fmt & kFmtMask, ext = (fmt & kFmtExt) ? 1 : 0;
+    const int vec_ok = aligned16(y) && ((reinterpret_cast<uintptr_t>(code) & 3u) == 0);
+    const int g = grid_for(n);
+    hipStream_t st = as_stream(stream);
+    if (f == kFmtSfp7) hipLaunchKernelGGL((k_decode<kFmtSfp7>), dim3(g), dim3(kThreads), 0, st, code, y, n, ext, vec_ok);
+    else if (f == kFmtAct8 || f == kFmtW8) hipLaunchKernelGGL((k_decode<kFmtAct8>), dim3(g), dim3(kThreads), 0, st, code, y, n, ext, vec_ok);
+    else return fail(SLFP_ERR_BAD_ARG, "unknown codec format %d", fmt);
+    return check_launch("slfp decode kernel");
+}
+
+int slfp_nchw_to_nhwc_f32(const float* x, float* y, int64_t n, int64_t c, int64_t h, int64_t w, void* stream) {
+    return launch_transpose(x, y, n, c, h * w, as_stream(stream));  // [C][HW] -> [HW][C]
+}
+
+int slfp_nhwc_to_nchw_f32(const float* x, float* y, int64_t n, int64_t c, int64_t h, int64_t w, void* stream) {
+    return launch_transpose(x, y, n, h * w, c, as_stream(stream));  // [HW][C] -> [C][HW]
+}
+
+}  // extern "C"

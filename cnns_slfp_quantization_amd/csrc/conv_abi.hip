@@ -1,0 +1,240 @@
+// conv_abi.hip -- C ABI for the quantized conv2d / linear forward (include/slfp.h):
+// descriptor validation, kernel selection, weight preparation, dispatch.
+#include <cstring>
+#include "slfp_device.hpp"
+#include "slfp_host.hpp"
+
+namespace slfp {
+
+static size_t round256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+int make_plan(const slfp_conv2d_desc* d, ConvPlan* plan) {
+    if (!d || !plan) return fail(SLFP_ERR_BAD_ARG, "conv2d: null descriptor");
+    if (d->n <= 0 || d->c_in <= 0 || d->h <= 0 || d->w <= 0 || d->c_out <= 0 || d->kh <= 0 || d->kw <= 0)
+        return fail(SLFP_ERR_SHAPE, "conv2d: non-positive size");
+    if (d->stride_h <= 0 || d->stride_w <= 0 || d->dil_h <= 0 || d->dil_w <= 0 || d->pad_h < 0 || d->pad_w < 0)
+        return fail(SLFP_ERR_SHAPE, "conv2d: bad stride/dilation/padding");
+    if (d->groups <= 0 || d->c_in % d->groups || d->c_out % d->groups)
+        return fail(SLFP_ERR_SHAPE, "conv2d: groups=%d does not divide C_in=%lld / C_out=%lld", d->groups,
+                    (long long)d->c_in, (long long)d->c_out);
+    if (d->qbits != 8 && d->qbits != 7)
+        return fail(SLFP_ERR_BAD_ARG, "conv2d: qbits must be 8 (SLFP<3,4>) or 7 (SFP<3,3>), got %d", d->qbits);
+    if ((d->x_layout != SLFP_LAYOUT_NCHW && d->x_layout != SLFP_LAYOUT_NHWC) ||
+        (d->y_layout != SLFP_LAYOUT_NCHW && d->y_layout != SLFP_LAYOUT_NHWC))
+        return fail(SLFP_ERR_BAD_ARG, "conv2d: unknown layout");
+    if (!(d->ka > 0.f) || !(d->kw_scale > 0.f)) return fail(SLFP_ERR_BAD_ARG, "conv2d: Ka and Kw must be > 0");
+    if (d->mfma_passes != SLFP_MFMA_DEFAULT && d->mfma_passes != SLFP_MFMA_F16X1 && d->mfma_passes != SLFP_MFMA_F16X3)
+        return fail(SLFP_ERR_BAD_ARG, "conv2d: mfma_passes must be 0, 1 or 3");
+    const int64_t eh = d->h + 2 * (int64_t)d->pad_h - (int64_t)d->dil_h * (d->kh - 1) - 1;
+    const int64_t ew = d->w + 2 * (int64_t)d->pad_w - (int64_t)d->dil_w * (d->kw - 1) - 1;
+    if (eh < 0 || ew < 0) return fail(SLFP_ERR_SHAPE, "conv2d: kernel larger than the padded input");
+    plan->h_out = eh / d->stride_h + 1;
+    plan->w_out = ew / d->stride_w + 1;
+    if (d->n > 0x7FFFFFFF || d->h > 0x7FFFFFFF || d->w > 0x7FFFFFFF || d->c_in > 0x7FFFFFFF || d->c_out > 0x7FFFFFFF)
+        return fail(SLFP_ERR_UNSUPPORTED, "conv2d: dimension exceeds 2^31");
+    plan->fmt_act = d->qbits == 8 ? kFmtAct8 : kFmtSfp7;
+    plan->fmt_w = d->qbits == 8 ? kFmtW8 : kFmtSfp7;
+    plan->passes = d->qbits == 7 ? 1 : (d->mfma_passes == SLFP_MFMA_F16X1 ? 1 : 3);
+    plan->k_pad = plan->n_pad = 0;
+    plan->s1 = d->ka;
+    plan->s2 = d->kw_scale;
+    const int64_t cg = d->c_in / d->groups;
+    const bool sq_stride = d->stride_h == d->stride_w;
+    if (d->groups == d->c_in && d->c_out == d->c_in && d->kh == 3 && d->kw == 3 && d->dil_h == 1 && d->dil_w == 1 &&
+        sq_stride && (d->stride_h == 1 || d->stride_h == 2) && d->pad_h == d->pad_w && d->pad_h <= 2 &&
+        (d->c_in % 4) == 0) {
+        plan->family = kDw3x3;
+        plan->wprep_bytes = round256((size_t)9 * d->c_in * sizeof(float));
+    } else if (d->kh == 1 && d->kw == 1 && d->groups == 1 && d->pad_h == 0 && d->pad_w == 0 && sq_stride &&
+               (d->c_in % 4) == 0 && (d->c_out % 4) == 0) {
+        plan->family = kPointwise;
+        plan->k_pad = ceil_div(d->c_in, 64) * 64;
+        plan->n_pad = ceil_div(d->c_out, 64) * 64;
+        plan->wprep_bytes = round256((size_t)2 * plan->k_pad * plan->n_pad * sizeof(_Float16));
+    } else {
+        plan->family = kDirect;
+        plan->wprep_bytes = round256((size_t)d->kh * d->kw * cg * d->c_out * sizeof(float));
+    }
+    return SLFP_OK;
+}
+
+// One thread per OIHW weight element: weight_q = QW(w / Kw) (utils/conv2d_func.py:22), written
+// in the layout the selected kernel family reads.
+template <int FMT>
+__global__ __launch_bounds__(256) void k_prepare(const float* __restrict__ w, void* __restrict__ prep,
+                                                 float* __restrict__ wq_oihw, int64_t total, int O, int Cg, int KH,
+                                                 int KW, float kw_scale, int family, int KS, int64_t plane) {
+    __shared__ uint32_t sT[16];
+    lut_fill(sT);
+    __syncthreads();
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const float q = quantize_scaled<FMT>(w[idx], kw_scale, sT);
+    if (wq_oihw) wq_oihw[idx] = q;
+    int64_t r = idx;
+    const int kw = (int)(r % KW); r /= KW;
+    const int kh = (int)(r % KH); r /= KH;
+    const int ci = (int)(r % Cg); r /= Cg;
+    const int o = (int)r;
+    if (family == kDw3x3) {
+        reinterpret_cast<float*>(prep)[(size_t)(kh * 3 + kw) * O + o] = q;  // [9][C]
+    } else if (family == kDirect) {
+        reinterpret_cast<float*>(prep)[((size_t)(kh * KW + kw) * Cg + ci) * O + o] = q;  // [KH][KW][Cg][O]
+    } else {
+        // MFMA 16x16x32 A-fragment order: tile (o/16, k/32), lane = ((k%32)/8)*16 + o%16, elem k%8
+        const int nt = o >> 4, row = o & 15, ks = ci >> 5, kq = (ci & 31) >> 3, j = ci & 7;
+        const size_t at = (((size_t)nt * KS + ks) * 64 + (size_t)(kq * 16 + row)) * 8 + j;
+        const float v = 16.0f * q;  // 2^4 pre-scale (exact), see conv_pw.hip
+        const _Float16 hi = (_Float16)v;
+        _Float16* blob = reinterpret_cast<_Float16*>(prep);
+        blob[at] = hi;
+        blob[plane + at] = (_Float16)(v - (float)hi);
+    }
+}
+
+int launch_prepare_weights(const slfp_conv2d_desc& d, const ConvPlan& p, const float* w_oihw, void* wprep,
+                           float* weight_q_oihw, hipStream_t stream) {
+    const int Cg = (int)(d.c_in / d.groups);
+    const int64_t total = d.c_out * Cg * d.kh * d.kw;
+    if (p.family == kPointwise) {
+        if (hipMemsetAsync(wprep, 0, p.wprep_bytes, stream) != hipSuccess) return check_launch("hipMemsetAsync(wprep)");
+    }
+    const int64_t plane = p.k_pad * p.n_pad;
+    const int KS = (int)(p.k_pad / 32);
+    const unsigned grid = (unsigned)ceil_div(total, 256);
+    if (p.fmt_w == kFmtW8)
+        hipLaunchKernelGGL((k_prepare<kFmtW8>), dim3(grid), dim3(256), 0, stream, w_oihw, wprep, weight_q_oihw, total,
+                           (int)d.c_out, Cg, (int)d.kh, (int)d.kw, d.kw_scale, (int)p.family, KS, plane);
+    else
+        hipLaunchKernelGGL((k_prepare<kFmtSfp7>), dim3(grid), dim3(256), 0, stream, w_oihw, wprep, weight_q_oihw, total,
+                           (int)d.c_out, Cg, (int)d.kh, (int)d.kw, d.kw_scale, (int)p.family, KS, plane);
+    return check_launch("slfp weight prepare kernel");
+}
+
+static const char* family_name(const ConvPlan& p) {
+    switch (p.family) {
+        case kDw3x3: return "dw3x3_nhwc";
+        case kPointwise: return p.fmt_act == kFmtSfp7 ? "pw_mfma_f16_exact" : (p.passes == 3 ? "pw_mfma_f16x3" : "pw_mfma_f16x1");
+        default: return "direct_nhwc";
+    }
+}
+
+}  // namespace slfp
+
+using namespace slfp;
+
+extern "C" {
+
+int slfp_conv2d_out_shape(const slfp_conv2d_desc* d, int64_t* h_out, int64_t* w_out) {
+    ConvPlan p;
+    const int rc = make_plan(d, &p);
+    if (rc != SLFP_OK) return rc;
+    if (h_out) *h_out = p.h_out;
+    if (w_out) *w_out = p.w_out;
+    return SLFP_OK;
+}
+
+const char* slfp_conv2d_kernel_name(const slfp_conv2d_desc* d) {
+    ConvPlan p;
+    if (make_plan(d, &p) != SLFP_OK) return "invalid";
+    return family_name(p);
+}
+
+size_t slfp_conv2d_wprep_bytes(const slfp_conv2d_desc* d) {
+    ConvPlan p;
+    if (make_plan(d, &p) != SLFP_OK) return 0;
+    return p.wprep_bytes;
+}
+
+int slfp_conv2d_prepare_weights(const slfp_conv2d_desc* d, const float* w_oihw, void* wprep, float* weight_q_oihw,
+                                void* stream) {
+    ConvPlan p;
+    const int rc = make_plan(d, &p);
+    if (rc != SLFP_OK) return rc;
+    if (!w_oihw || !wprep) return fail(SLFP_ERR_BAD_ARG, "slfp_conv2d_prepare_weights: null pointer");
+    if (!aligned16(wprep)) return fail(SLFP_ERR_ALIGNMENT, "slfp_conv2d_prepare_weights: wprep must be 16-byte aligned");
+    return launch_prepare_weights(*d, p, w_oihw, wprep, weight_q_oihw, as_stream(stream));
+}
+
+size_t slfp_conv2d_workspace_bytes(const slfp_conv2d_desc* d) {
+    ConvPlan p;
+    if (make_plan(d, &p) != SLFP_OK) return 0;
+    size_t b = 0;
+    if (d->x_layout == SLFP_LAYOUT_NCHW) b += round256((size_t)d->n * d->c_in * d->h * d->w * sizeof(float));
+    if (d->y_layout == SLFP_LAYOUT_NCHW) b += round256((size_t)d->n * d->c_out * p.h_out * p.w_out * sizeof(float));
+    return b;
+}
+
+int slfp_conv2d_fwd(const slfp_conv2d_desc* d, const float* x, const void* wprep, const float* bias, float* y,
+                    float* input_q, void* workspace, void* stream) {
+    ConvPlan p;
+    int rc = make_plan(d, &p);
+    if (rc != SLFP_OK) return rc;
+    if (!x || !wprep || !y) return fail(SLFP_ERR_BAD_ARG, "slfp_conv2d_fwd: null pointer");
+    if (!aligned16(x) || !aligned16(y) || !aligned16(wprep) || (bias && !aligned16(bias)))
+        return fail(SLFP_ERR_ALIGNMENT, "slfp_conv2d_fwd: x, y, wprep and bias must be 16-byte aligned");
+    hipStream_t st = as_stream(stream);
+    if (input_q) {  // the reference's self.input_q (utils/conv2d_func.py:21), in x's layout
+        rc = launch_quantize(x, input_q, (size_t)d->n * d->c_in * d->h * d->w, d->ka, p.fmt_act, st);
+        if (rc != SLFP_OK) return rc;
+    }
+    const size_t ws_need = slfp_conv2d_workspace_bytes(d);
+    if (ws_need && (!workspace || !aligned16(workspace)))
+        return fail(SLFP_ERR_BAD_ARG, "slfp_conv2d_fwd: %zu bytes of 16-byte aligned workspace required for NCHW", ws_need);
+    unsigned char* ws = reinterpret_cast<unsigned char*>(workspace);
+    const float* x_nhwc = x;
+    float* y_nhwc = y;
+    if (d->x_layout == SLFP_LAYOUT_NCHW) {
+        float* t = reinterpret_cast<float*>(ws);
+        ws += round256((size_t)d->n * d->c_in * d->h * d->w * sizeof(float));
+        rc = slfp_nchw_to_nhwc_f32(x, t, d->n, d->c_in, d->h, d->w, stream);
+        if (rc != SLFP_OK) return rc;
+        x_nhwc = t;
+    }
+    if (d->y_layout == SLFP_LAYOUT_NCHW) y_nhwc = reinterpret_cast<float*>(ws);
+    switch (p.family) {
+        case kDw3x3: rc = launch_dw3x3(*d, p, x_nhwc, reinterpret_cast<const float*>(wprep), bias, y_nhwc, st); break;
+        case kPointwise: rc = launch_pointwise(*d, p, x_nhwc, wprep, bias, y_nhwc, st); break;
+        default: rc = launch_direct(*d, p, x_nhwc, reinterpret_cast<const float*>(wprep), bias, y_nhwc, st); break;
+    }
+    if (rc != SLFP_OK) return rc;
+    if (d->y_layout == SLFP_LAYOUT_NCHW) rc = slfp_nhwc_to_nchw_f32(y_nhwc, y, d->n, d->c_out, p.h_out, p.w_out, stream);
+    return rc;
+}
+
+size_t slfp_linear_workspace_bytes(int64_t batch, int64_t in_f, int64_t out_f) {
+    slfp_conv2d_desc d;
+    memset(&d, 0, sizeof(d));
+    d.n = batch; d.c_in = in_f; d.h = 1; d.w = 1; d.c_out = out_f; d.kh = 1; d.kw = 1;
+    d.stride_h = d.stride_w = d.dil_h = d.dil_w = d.groups = 1;
+    d.x_layout = d.y_layout = SLFP_LAYOUT_NHWC; d.qbits = 8; d.ka = d.kw_scale = 1.f;
+    return slfp_conv2d_wprep_bytes(&d);
+}
+
+int slfp_linear_fwd(const float* x, const float* w, const float* bias, float* y, int64_t batch, int64_t in_f,
+                    int64_t out_f, float ka, float kw_scale, int qbits, int mfma_passes, void* workspace,
+                    void* stream) {
+    // Linear_Q.forward (utils/conv2d_func.py:60-65) = a 1x1 convolution over `batch` pixels,
+    // except that the reference divides the bias by Kw first and rescales by Kw first.
+    slfp_conv2d_desc d;
+    memset(&d, 0, sizeof(d));
+    d.n = batch; d.c_in = in_f; d.h = 1; d.w = 1; d.c_out = out_f; d.kh = 1; d.kw = 1;
+    d.stride_h = d.stride_w = d.dil_h = d.dil_w = d.groups = 1;
+    d.x_layout = d.y_layout = SLFP_LAYOUT_NHWC; d.qbits = qbits; d.ka = ka; d.kw_scale = kw_scale;
+    d.mfma_passes = mfma_passes;
+    ConvPlan p;
+    int rc = make_plan(&d, &p);
+    if (rc != SLFP_OK) return rc;
+    if (!x || !w || !y || !workspace) return fail(SLFP_ERR_BAD_ARG, "slfp_linear_fwd: null pointer");
+    if (!aligned16(x) || !aligned16(y) || !aligned16(workspace) || (bias && !aligned16(bias)))
+        return fail(SLFP_ERR_ALIGNMENT, "slfp_linear_fwd: pointers must be 16-byte aligned");
+    hipStream_t st = as_stream(stream);
+    rc = launch_prepare_weights(d, p, w, workspace, nullptr, st);  // the reference re-quantizes per call too
+    if (rc != SLFP_OK) return rc;
+    p.s1 = kw_scale;
+    p.s2 = ka;
+    if (p.family == kPointwise) return launch_pointwise(d, p, x, workspace, bias, y, st);
+    return launch_direct(d, p, x, reinterpret_cast<const float*>(workspace), bias, y, st);
+}
+
+}  // extern "C"

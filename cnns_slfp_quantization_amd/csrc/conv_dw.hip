@@ -1,0 +1,179 @@
+// conv_dw.hip -- SLFP-quantized depthwise 3x3 convolution, NHWC, gfx950.
+//
+// Replaces Conv2d_Q.forward (utils/conv2d_func.py:20-25) for groups == C_in == C_out,
+// 3x3 kernels (the 13 "dw" layers of MobileNetV1, nets_imgnet/mobilenetv1.py:27).
+//
+// HBM-bound (1.7 flop/B): algorithmic traffic is 4 B read + 4 B written per element.
+//   * one workgroup = one (image, TH x TW output tile, CB-channel group);
+//   * LOAD phase: the (TH-1)*S+3 x (TW-1)*S+3 input halo tile is read from HBM with
+//     16-byte loads, channels across lanes (a pixel's CB channels are one contiguous
+//     128/256-byte segment), x/Ka + SLFP encode applied ONCE per element inline, and the
+//     dequantized float32 written to LDS (zero where the conv pads);
+//   * COMPUTE phase: every thread owns 4 channels (its 9x4 weights live in registers),
+//     reads 9 ds_read_b128 per output float4, FMAs in float32, rescales *Ka*Kw with the
+//     reference's two roundings, and stores 16 bytes.
+// For stride 2 the tile's columns are stored de-interleaved (even columns, then odd) so
+// that the 8 pixels a wave reads for one tap are contiguous in LDS (no bank conflicts).
+#include "slfp_device.hpp"
+#include "slfp_host.hpp"
+
+namespace slfp {
+
+constexpr int kDwThreads = 256;
+
+struct DwParams {
+    int N, H, W, C, Ho, Wo;
+    int TH, TW, tiles_h, tiles_w;
+    int CB, cgroups;   // channels per block (multiple of 4, CB/4 divides 256), #channel groups
+    int pad;
+    int IH, IW, IWh;   // input tile extent; IWh = (IW+1)/2 (stride-2 de-interleave)
+    float ka, kw;
+    uint32_t nblocks;
+};
+
+template <int FMT, int S>
+__global__ __launch_bounds__(kDwThreads) void k_dw3x3(const float* __restrict__ x, const float* __restrict__ wq,
+                                                      const float* __restrict__ bias, float* __restrict__ y,
+                                                      const DwParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* sT = reinterpret_cast<uint32_t*>(smem);      // 16 dwords
+    float* tile = reinterpret_cast<float*>(smem + 64);     // [IH][IW][CB]
+    lut_fill(sT);
+
+    // logical block id -> (channel group, tile_w, tile_h, image); XCD-contiguous so that
+    // tiles sharing a halo are served by the same L2.
+    uint32_t b = xcd_remap(blockIdx.x, p.nblocks);
+    const int cg = b % p.cgroups; b /= p.cgroups;
+    const int tw = b % p.tiles_w; b /= p.tiles_w;
+    const int th = b % p.tiles_h; b /= p.tiles_h;
+    const int n = b;
+
+    const int cb4 = p.CB >> 2;
+    const int c0 = cg * p.CB;
+    const int h_in0 = th * p.TH * S - p.pad, w_in0 = tw * p.TW * S - p.pad;
+    __syncthreads();
+
+    // ---------------- LOAD + ENCODE phase ----------------
+    const int n_in = p.IH * p.IW * cb4;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    constexpr int U = 4;  // loads kept in flight per thread
+    for (int base = threadIdx.x; base < n_in; base += kDwThreads * U) {
+        float4 v[U];
+        int dst[U];
+        bool live[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int item = base + u * kDwThreads;
+            const int c4 = item % cb4;
+            const int pix = item / cb4;
+            const int iw = pix % p.IW, ih = pix / p.IW;
+            const int gh = h_in0 + ih, gw = w_in0 + iw, c = c0 + c4 * 4;
+            live[u] = item < n_in;
+            const bool inb = live[u] && gh >= 0 && gh < p.H && gw >= 0 && gw < p.W && c < p.C;
+            const int slot = (S == 2) ? ((iw & 1) * p.IWh + (iw >> 1)) : iw;
+            dst[u] = (ih * p.IW + slot) * p.CB + c4 * 4;
+            v[u] = zero4;
+            if (inb) v[u] = *reinterpret_cast<const float4*>(x + ((((size_t)n * p.H + gh) * p.W + gw) * p.C + c));
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!live[u]) continue;
+            float4 q;
+            // Q(0/Ka) == 0, so padded / out-of-range zeros go through the same path.
+            q.x = quantize_scaled<FMT>(v[u].x, p.ka, sT);
+            q.y = quantize_scaled<FMT>(v[u].y, p.ka, sT);
+            q.z = quantize_scaled<FMT>(v[u].z, p.ka, sT);
+            q.w = quantize_scaled<FMT>(v[u].w, p.ka, sT);
+            *reinterpret_cast<float4*>(tile + dst[u]) = q;
+        }
+    }
+
+    // this thread's 4 channels x 9 taps (c4 is the same for every item of a thread
+    // because cb4 divides the block size)
+    const int my_c4 = threadIdx.x % cb4;
+    const int my_c = c0 + my_c4 * 4;
+    float4 wt[9];
+    float4 bq = zero4;
+    if (my_c < p.C) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const float4*>(wq + (size_t)t * p.C + my_c);
+        if (bias) {  // bias_q = bias / Ka / Kw (utils/conv2d_func.py:44)
+            const float4 bb = *reinterpret_cast<const float4*>(bias + my_c);
+            bq = make_float4((bb.x / p.ka) / p.kw, (bb.y / p.ka) / p.kw, (bb.z / p.ka) / p.kw, (bb.w / p.ka) / p.kw);
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wt[t] = zero4;
+    }
+    __syncthreads();
+
+    // ---------------- COMPUTE phase ----------------
+    const int n_out = p.TH * p.TW * cb4;
+    for (int item = threadIdx.x; item < n_out; item += kDwThreads) {
+        const int pix = item / cb4;
+        const int ow = pix % p.TW, oh = pix / p.TW;
+        const int goh = th * p.TH + oh, gow = tw * p.TW + ow;
+        if (goh >= p.Ho || gow >= p.Wo || my_c >= p.C) continue;
+        float4 acc = bq;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const float* row = tile + (size_t)((oh * S + kh) * p.IW) * p.CB + my_c4 * 4;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iw = ow * S + kw;
+                const int slot = (S == 2) ? ((iw & 1) * p.IWh + (iw >> 1)) : iw;
+                const float4 a = *reinterpret_cast<const float4*>(row + slot * p.CB);
+                const float4 w = wt[kh * 3 + kw];
+                acc.x = fmaf(a.x, w.x, acc.x);
+                acc.y = fmaf(a.y, w.y, acc.y);
+                acc.z = fmaf(a.z, w.z, acc.z);
+                acc.w = fmaf(a.w, w.w, acc.w);
+            }
+        }
+        float4 r;  // (out * Ka) * Kw: two float32 roundings, as utils/conv2d_func.py:24
+        r.x = (acc.x * p.ka) * p.kw;
+        r.y = (acc.y * p.ka) * p.kw;
+        r.z = (acc.z * p.ka) * p.kw;
+        r.w = (acc.w * p.ka) * p.kw;
+        *reinterpret_cast<float4*>(y + ((((size_t)n * p.Ho + goh) * p.Wo + gow) * p.C + my_c)) = r;
+    }
+}
+
+int launch_dw3x3(const slfp_conv2d_desc& d, const ConvPlan& plan, const float* x, const float* wq9c,
+                 const float* bias, float* y, hipStream_t stream) {
+    DwParams p;
+    p.N = (int)d.n; p.H = (int)d.h; p.W = (int)d.w; p.C = (int)d.c_in;
+    p.Ho = (int)plan.h_out; p.Wo = (int)plan.w_out;
+    const int S = d.stride_h;
+    // channel group: largest power-of-two multiple of 4 (<= 64) dividing C
+    int CB = 4;
+    while (CB < 64 && p.C % (CB * 2) == 0) CB *= 2;
+    const int tmax = (S == 1) ? 14 : 7;
+    p.TH = p.Ho < tmax ? p.Ho : tmax;
+    p.TW = p.Wo < tmax ? p.Wo : tmax;
+    p.tiles_h = (int)ceil_div(p.Ho, p.TH);
+    p.tiles_w = (int)ceil_div(p.Wo, p.TW);
+    p.IH = (p.TH - 1) * S + 3;
+    p.IW = (p.TW - 1) * S + 3;
+    // keep the halo tile within 40 KiB of LDS (>= 3 workgroups per CU)
+    while (CB > 4 && (size_t)p.IH * p.IW * CB * sizeof(float) > 40 * 1024) CB /= 2;
+    p.CB = CB;
+    p.cgroups = p.C / CB;
+    p.pad = d.pad_h;
+    p.IWh = (p.IW + 1) / 2;
+    p.ka = d.ka; p.kw = d.kw_scale;
+    const int64_t nblocks = (int64_t)p.N * p.tiles_h * p.tiles_w * p.cgroups;
+    if (nblocks > 0x7FFFFFFF) return fail(SLFP_ERR_UNSUPPORTED, "dw3x3: grid too large");
+    p.nblocks = (uint32_t)nblocks;
+    const size_t lds = 64 + (size_t)p.IH * p.IW * p.CB * sizeof(float);
+    if (lds > 64 * 1024) return fail(SLFP_ERR_UNSUPPORTED, "dw3x3: tile needs %zu B of LDS", lds);
+    const bool a8 = plan.fmt_act == kFmtAct8;
+#define SLFP_DW_LAUNCH(FMT, SS) \
+    hipLaunchKernelGGL((k_dw3x3<FMT, SS>), dim3(p.nblocks), dim3(kDwThreads), lds, stream, x, wq9c, bias, y, p)
+    if (S == 1) { if (a8) SLFP_DW_LAUNCH(kFmtAct8, 1); else SLFP_DW_LAUNCH(kFmtSfp7, 1); }
+    else        { if (a8) SLFP_DW_LAUNCH(kFmtAct8, 2); else SLFP_DW_LAUNCH(kFmtSfp7, 2); }
+#undef SLFP_DW_LAUNCH
+    return check_launch("slfp dw3x3 kernel");
+}
+
+}  // namespace slfp

@@ -1,0 +1,60 @@
+// slfp_host.hpp -- host-side helpers shared by the translation units of libslfp_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/slfp.h"
+
+namespace slfp {
+
+// thread-local last-error text (slfp_last_error()).
+void set_error(const char* fmt, ...);
+int fail(int code, const char* fmt, ...);
+// Returns SLFP_OK or SLFP_ERR_HIP (and records the HIP error string) after a launch.
+int check_launch(const char* what);
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Kernel families (slfp_conv2d_kernel_name reports them).
+enum KernelFamily { kDw3x3 = 0, kPointwise = 1, kDirect = 2 };
+
+struct ConvPlan {
+    KernelFamily family;
+    int fmt_act;   // kFmtAct8 | kFmtSfp7
+    int fmt_w;     // kFmtW8   | kFmtSfp7
+    int passes;    // MFMA passes for the pointwise family (1 or 3)
+    int64_t h_out, w_out;
+    float s1, s2;  // epilogue: out = ((acc + bias/s1/s2) * s1) * s2  (conv: Ka,Kw; linear: Kw,Ka)
+    // pointwise: padded K (multiple of 64) and N (multiple of 64) of the fragment-ordered blob
+    int64_t k_pad, n_pad;
+    size_t wprep_bytes;
+};
+
+// Validates `d` and fills `plan`; returns SLFP_OK or an error status (error text recorded).
+int make_plan(const slfp_conv2d_desc* d, ConvPlan* plan);
+
+// ---- launchers implemented next to their kernels (all NHWC, all async on `stream`) ----
+int launch_quantize(const float* x, float* y, size_t n, float scale, int fmt, hipStream_t stream);
+int launch_dw3x3(const slfp_conv2d_desc& d, const ConvPlan& p, const float* x, const float* wq9c,
+                 const float* bias, float* y, hipStream_t stream);
+int launch_pointwise(const slfp_conv2d_desc& d, const ConvPlan& p, const float* x, const void* wfrag,
+                     const float* bias, float* y, hipStream_t stream);
+int launch_direct(const slfp_conv2d_desc& d, const ConvPlan& p, const float* x, const float* wq_hwio,
+                  const float* bias, float* y, hipStream_t stream);
+int launch_prepare_weights(const slfp_conv2d_desc& d, const ConvPlan& p, const float* w_oihw, void* wprep,
+                           float* weight_q_oihw, hipStream_t stream);
+
+// XCD-aware block remap (MI355X: 8 XCDs, blocks are dealt round-robin over them, so
+// blocks b and b+8 share an L2).  Maps the hardware block id to a logical id such that
+// each XCD owns a CONTIGUOUS range of logical ids: neighbouring tiles (shared halos,
+// shared X rows of a column-split GEMM) then hit the same L2.  Bijective for any grid.
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nblocks) {
+    const uint32_t xcd = bid & 7u, slot = bid >> 3;
+    const uint32_t q = nblocks >> 3, r = nblocks & 7u;
+    const uint32_t base = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
+    return base + slot;
+}
+
+}  // namespace slfp

@@ -1,0 +1,52 @@
+"""Batch-axis sharding of the quantized conv path over the GPUs of one node.
+
+The reference has no distributed code at all.  Images are independent
+units through the whole hot path, so the MI355X design is: one process per GPU
+(torch.distributed, backend "nccl" == RCCL over xGMI), each rank owns a contiguous slice
+of the batch, and the ONLY collective is a one-time broadcast of the quantized (prepared)
+weight blobs from rank 0 -- all layers flattened into one bucket so that it is a single
+large RCCL broadcast instead of 27-53 small ones.  There is no per-step exchange.
+The same code runs on CPU tensors with the gloo backend (tests).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total, rank, world):
+    """Contiguous [lo, hi) slice of `total` items owned by `rank` (sizes differ by <= 1)."""
+    if world <= 0 or not 0 <= rank < world:
+        raise ValueError(f"bad rank/world {rank}/{world}")
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def broadcast_blobs(blobs, src=0, group=None):
+    """Broadcast a list of uint8 tensors (the per-layer prepared weight blobs) from `src`
+    as ONE flat bucket; the tensors are overwritten in place on the other ranks."""
+    if not blobs:
+        return blobs
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return blobs
+    sizes = [int(b.numel()) for b in blobs]
+    flat = torch.empty(sum(sizes), dtype=torch.uint8, device=blobs[0].device)
+    if dist.get_rank(group) == src:
+        off = 0
+        for b, n in zip(blobs, sizes):
+            flat[off:off + n].copy_(b.reshape(-1))
+            off += n
+    dist.broadcast(flat, src=src, group=group)
+    off = 0
+    for b, n in zip(blobs, sizes):
+        b.reshape(-1).copy_(flat[off:off + n])
+        off += n
+    return blobs
+
+
+def gather_outputs(local, group=None):
+    """Optional final all-gather of per-rank outputs (e.g. logits) along dim 0."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local
+    parts = [torch.empty_like(local) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(parts, local.contiguous(), group=group)
+    return torch.cat(parts, dim=0)

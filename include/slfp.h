@@ -1,0 +1,130 @@
+/*
+ * slfp.h -- C ABI of libslfp_hip.so: the MI355X (gfx950) SLFP<3,4> / SFP<3,3> quantized
+ * conv2d forward path.
+ *
+ * This is the drop-in boundary for the hot path of happyxtt/CNNs_SLFP_quantization:
+ *   utils/sfp_quant.py    quantize_act / quantize_weight (fake-quant codecs)
+ *   utils/conv2d_func.py  Conv2d_Q.forward (conv2d_Q, conv2d_Q_bias), Linear_Q.forward
+ * Every entry point takes plain device pointers and sizes (no torch types), is
+ * asynchronous on the hipStream_t passed as `void* stream` (NULL = the default stream),
+ * never allocates, never synchronises, never throws, and returns an int status
+ * (0 = ok, < 0 = error; slfp_last_error() gives the text).  The reference raises Python
+ * exceptions (an assert at sfp_quant.py:138 and shape errors from F.conv2d); the host
+ * binding maps non-zero statuses to the same exception types.
+ *
+ * Threading: no global mutable state except a thread-local last-error string; safe to
+ * call from any host thread; one device per process is assumed (multi-GPU = one process
+ * per GPU, as torch.distributed/RCCL launches them).
+ */
+#ifndef SLFP_H_
+#define SLFP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLFP_ABI_VERSION 1
+
+/* status codes */
+#define SLFP_OK 0
+#define SLFP_ERR_BAD_ARG (-1)     /* null pointer, bad enum, non-positive size, bad Qbits */
+#define SLFP_ERR_SHAPE (-2)       /* inconsistent conv geometry (what F.conv2d would reject) */
+#define SLFP_ERR_UNSUPPORTED (-3) /* valid but not implemented on this path (e.g. dilation with NCHW) */
+#define SLFP_ERR_ALIGNMENT (-4)   /* a pointer is not aligned as the kernel needs (16 B) */
+#define SLFP_ERR_HIP (-5)         /* a HIP runtime call failed (launch error etc.) */
+
+/* codec formats (the `fmt` argument) */
+#define SLFP_FMT_ACT8 0 /* quantize_act(8):    SLFP<3,4> activations, utils/sfp_quant.py:80-96 */
+#define SLFP_FMT_W8 1   /* quantize_weight(8): SLFP<3,4> weights,     utils/sfp_quant.py:32-47 */
+#define SLFP_FMT_SFP7 2 /* quantize_{act,weight}(7): SFP<3,3>,        utils/sfp_quant.py:14-30,63-78 */
+#define SLFP_FMT_EXT 4  /* OR-able: extended code points (exact zero = 0x01, clamp literal =
+                           sign|0x02) so that decode(encode(x)) == quantize(x) bit for bit */
+
+/* tensor layouts */
+#define SLFP_LAYOUT_NCHW 0 /* the reference's layout (contiguous NCHW) */
+#define SLFP_LAYOUT_NHWC 1 /* channels-last: the native layout of the HIP kernels */
+
+/* pointwise/implicit-GEMM MFMA operand precision (slfp_conv2d_desc.mfma_passes) */
+#define SLFP_MFMA_DEFAULT 0 /* library default */
+#define SLFP_MFMA_F16X1 1   /* one fp16 MFMA pass: ~2.5e-4 tensor-relative error on SLFP<3,4> */
+#define SLFP_MFMA_F16X3 3   /* hi/lo split, three passes: float32-equivalent (~1e-6) */
+
+int slfp_version(void);
+/* Text of the last error on the calling thread ("" if none). Never NULL. */
+const char* slfp_last_error(void);
+/* Number of visible HIP devices (0 if none / runtime unavailable). */
+int slfp_device_count(void);
+
+/* ---- codec: replaces quantize_act(k) / quantize_weight(k) .forward ------------------
+ * q = x[i] / scale_div is an IEEE float32 division, exactly as `input/self.Ka`
+ * (utils/conv2d_func.py:21-22) with the float64 0-dim scale cast to float32.           */
+
+/* code[i] = canonical code of Q_fmt(q): sign<<7 | (E+4)<<4 | m  (Qbits 8)
+ *                                        sign<<6 | (E+4)<<3 | m  (Qbits 7)
+ * (bit layout from the comments at utils/sfp_quant.py:95 and :125). */
+int slfp_encode_f32(const float* x, uint8_t* code, size_t n, float scale_div, int fmt, void* stream);
+/* y[i] = float32 value of code[i] (inverse of the above; with SLFP_FMT_EXT exact). */
+int slfp_decode_f32(const uint8_t* code, float* y, size_t n, int fmt, void* stream);
+/* y[i] = Q_fmt(q) as float32: bit-identical to what qfn.forward returns
+ * (utils/sfp_quant.py:10-48, :59-97).  x == y (in place) is allowed. */
+int slfp_quantize_f32(const float* x, float* y, size_t n, float scale_div, int fmt, void* stream);
+
+/* ---- conv2d: replaces Conv2d_Q.forward (utils/conv2d_func.py:20-25 and :41-47) ------ */
+
+typedef struct slfp_conv2d_desc {
+    int64_t n, c_in, h, w;    /* input  N x C_in x H x W (logical NCHW sizes)              */
+    int64_t c_out, kh, kw;    /* weight C_out x (C_in/groups) x KH x KW                     */
+    int32_t stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, groups;
+    int32_t x_layout, y_layout; /* SLFP_LAYOUT_*: memory layout of x and of y                 */
+    int32_t qbits;            /* 8 = SLFP<3,4>, 7 = SFP<3,3>  (32 is a host-side passthrough) */
+    float ka, kw_scale;       /* float32(Ka), float32(Kw): the module's calibration scales    */
+    int32_t mfma_passes;      /* SLFP_MFMA_*                                                   */
+    int32_t reserved;
+} slfp_conv2d_desc;
+
+/* Validates the geometry; writes the output spatial size. */
+int slfp_conv2d_out_shape(const slfp_conv2d_desc* d, int64_t* h_out, int64_t* w_out);
+/* Which kernel family slfp_conv2d_fwd will run for this descriptor (for logs/tests):
+ * a static string such as "dw3x3_nhwc", "pw_mfma_f16x3", "direct_nhwc". */
+const char* slfp_conv2d_kernel_name(const slfp_conv2d_desc* d);
+
+/* Bytes of the prepared-weight blob for this layer (device memory the caller owns). */
+size_t slfp_conv2d_wprep_bytes(const slfp_conv2d_desc* d);
+/* Quantize the float32 OIHW weights once: weight_q = QW(w / Kw) (conv2d_func.py:22) and
+ * lay them out for the kernel this descriptor selects.  weight_q_oihw (optional, may be
+ * NULL) receives the reference's `self.weight_q` tensor (float32, OIHW).  The reference
+ * re-quantizes the weights on every forward; callers cache the blob and call this again
+ * whenever the weight tensor changes. */
+int slfp_conv2d_prepare_weights(const slfp_conv2d_desc* d, const float* w_oihw, void* wprep,
+                                float* weight_q_oihw, void* stream);
+/* Bytes of scratch slfp_conv2d_fwd needs for this descriptor (0 for the native NHWC path;
+ * non-zero when a layout conversion is involved). */
+size_t slfp_conv2d_workspace_bytes(const slfp_conv2d_desc* d);
+/* y = conv2d(QA(x/Ka), weight_q, bias/Ka/Kw) * Ka * Kw.
+ * bias: NULL for conv2d_Q (conv2d_func.py:20-25), float32[C_out] for conv2d_Q_bias (:41-47).
+ * input_q (optional, may be NULL): receives QA(x/Ka) in x's layout (the reference's
+ * `self.input_q`).  workspace: slfp_conv2d_workspace_bytes(d) bytes or NULL if that is 0. */
+int slfp_conv2d_fwd(const slfp_conv2d_desc* d, const float* x, const void* wprep, const float* bias,
+                    float* y, float* input_q, void* workspace, void* stream);
+
+/* ---- linear: replaces Linear_Q.forward (utils/conv2d_func.py:60-65) -------------------
+ * out = linear(QA(x/Ka), QW(w/Kw), bias/Kw/Ka) * Kw * Ka   (note the Kw-first order).
+ * x: [batch, in_f] row-major, w: [out_f, in_f] row-major, bias: [out_f] or NULL.  The weights
+ * are re-quantized on every call (as the reference does) into `workspace`
+ * (slfp_linear_workspace_bytes bytes of device memory).                                   */
+size_t slfp_linear_workspace_bytes(int64_t batch, int64_t in_f, int64_t out_f);
+int slfp_linear_fwd(const float* x, const float* w, const float* bias, float* y, int64_t batch,
+                    int64_t in_f, int64_t out_f, float ka, float kw_scale, int qbits, int mfma_passes,
+                    void* workspace, void* stream);
+
+/* ---- layout helpers (the reference is NCHW; the kernels are NHWC) -------------------- */
+int slfp_nchw_to_nhwc_f32(const float* x, float* y, int64_t n, int64_t c, int64_t h, int64_t w, void* stream);
+int slfp_nhwc_to_nchw_f32(const float* x, float* y, int64_t n, int64_t c, int64_t h, int64_t w, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLFP_H_ */

@@ -1,0 +1,41 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def codec_golden():
+    return np.load(os.path.join(GOLDEN, "codec_golden.npz"))
+
+
+@pytest.fixture(scope="session")
+def conv_golden():
+    return np.load(os.path.join(GOLDEN, "conv_golden.npz"))
+
+
+def same_bits(a, b):
+    """bit equality of two uint32 views, every NaN equal to every NaN."""
+    a = np.asarray(a).view(np.uint32).ravel()
+    b = np.asarray(b).view(np.uint32).ravel()
+    na = (a & 0x7FFFFFFF) > 0x7F800000
+    nb = (b & 0x7FFFFFFF) > 0x7F800000
+    return bool(np.array_equal(na, nb) and np.array_equal(a[~na], b[~nb]))
+
+
+def rel_errors(y, ref):
+    """(max|d| / max|ref|, ||d||2 / ||ref||2): the tensor-relative parity metric."""
+    y = np.asarray(y, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    d = y - ref
+    return float(np.abs(d).max() / max(np.abs(ref).max(), 1e-30)), float(np.linalg.norm(d) / max(np.linalg.norm(ref), 1e-30))

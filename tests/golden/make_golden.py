@@ -28,8 +28,8 @@ import numpy as np
 warnings.filterwarnings("ignore")
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-sys.path.insert(0, ROOT)
-sys.path.insert(1, "/root/reference")
+sys.path.insert(0, "/root/reference")  # `utils` must be the REFERENCE package here
+sys.path.insert(1, ROOT)
 
 import torch  # noqa: E402
 

@@ -1,0 +1,348 @@
+"""GPU (MI355X): parity of the HIP path, called through the C ABI / the drop-in operator
+modules, against (1) the committed golden vectors generated from the imported reference
+and (2) the CPU oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star):
+  * codec (the SLFP/SFP quantize step): BIT-EXACT, float32 values and code bytes;
+  * conv output (post-dequant float32): tensor-relative error
+        max|d| <= tol * max|ref|   and   ||d||_2 <= tol * ||ref||_2
+    with tol = 1e-3 (north-star tolerance) for the single-pass fp16 MFMA mode and
+    tol = 1e-5 for every float32-equivalent path (dw, direct, fp16x3 pointwise, SFP<3,3>).
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_errors, same_bits
+from oracle import slfp_oracle as so
+from oracle import torch_port as tp
+
+pytestmark = pytest.mark.gpu
+
+TOL_EXACT = 1e-5   # float32-equivalent paths
+TOL_F16X1 = 1e-3   # north-star tolerance; measured ~2.5e-4
+FMT = {"act8": so.FMT_ACT8, "w8": so.FMT_W8, "act7": so.FMT_SFP7, "w7": so.FMT_SFP7}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from cnns_slfp_quantization_amd import _lib
+    L = _lib.load()  # raises if libslfp_hip.so is missing: no fallback
+    assert L.slfp_device_count() >= 1
+    return _lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def gpu_quantize(lib, x_np, scale, fmt, dev):
+    x = torch.from_numpy(np.ascontiguousarray(x_np)).to(dev)
+    y = torch.empty_like(x)
+    lib.check(lib.load().slfp_quantize_f32(x.data_ptr(), y.data_ptr(), x.numel(), float(np.float32(scale)), fmt, _stream()))
+    return y.cpu().numpy()
+
+
+def gpu_encode(lib, x_np, scale, fmt, dev):
+    x = torch.from_numpy(np.ascontiguousarray(x_np)).to(dev)
+    c = torch.empty(x.shape, dtype=torch.uint8, device=dev)
+    lib.check(lib.load().slfp_encode_f32(x.data_ptr(), c.data_ptr(), x.numel(), float(np.float32(scale)), fmt, _stream()))
+    return c.cpu().numpy()
+
+
+def gpu_decode(lib, c_np, fmt, dev):
+    c = torch.from_numpy(np.ascontiguousarray(c_np)).to(dev)
+    y = torch.empty(c.shape, dtype=torch.float32, device=dev)
+    lib.check(lib.load().slfp_decode_f32(c.data_ptr(), y.data_ptr(), c.numel(), fmt, _stream()))
+    return y.cpu().numpy()
+
+
+# ------------------------------------------------------------------ codec: bit-exact
+@pytest.mark.parametrize("name", list(FMT))
+def test_codec_golden_bit_exact(lib, dev, codec_golden, name):
+    x = codec_golden[name + "_in_bits"].view(np.float32)
+    assert same_bits(gpu_quantize(lib, x, 1.0, FMT[name], dev), codec_golden[name + "_out_bits"])
+
+
+def test_reference_kat(lib, dev, codec_golden):
+    y = gpu_quantize(lib, codec_golden["kat_in"], 1.0, so.FMT_ACT8, dev)
+    assert same_bits(y, codec_golden["kat_act8"])  # utils/sfp_quant.py:177-182
+
+
+def test_scaled_division_bit_exact(lib, dev, codec_golden):
+    x = codec_golden["div_in"]
+    for i, k in enumerate(codec_golden["div_scales_f64"]):
+        for name in ("act8", "w8", "act7"):
+            y = gpu_quantize(lib, x, np.float32(k), FMT[name], dev)
+            assert same_bits(y, codec_golden[f"div{i}_{name}_out_bits"]), (i, name)
+
+
+@pytest.mark.parametrize("fmt", [so.FMT_ACT8, so.FMT_W8, so.FMT_SFP7])
+def test_codec_vs_oracle_large_and_ragged(lib, dev, fmt):
+    rng = np.random.default_rng(11)
+    n = (1 << 22) + 3  # not a multiple of 4: exercises the scalar tail
+    x = np.exp2(rng.uniform(-9, 6, n)).astype(np.float32) * rng.choice([-1, 1], n).astype(np.float32)
+    x[::1001] = 0.0
+    x[5::7919] = np.float32(15.32165) * np.float32(0.171)  # sits on the clamp after division
+    k = np.float32(0.171)
+    assert same_bits(gpu_quantize(lib, x, k, fmt, dev), so.quantize(x, k, fmt))
+    for f in (fmt, fmt | so.FMT_EXT):
+        c = gpu_encode(lib, x, k, f, dev)
+        assert np.array_equal(c, so.encode(x, k, f))
+        assert same_bits(gpu_decode(lib, c, f, dev), so.decode(c, f))
+    # extended codes: decode(encode(x)) == quantize(x)
+    assert same_bits(gpu_decode(lib, gpu_encode(lib, x, k, fmt | so.FMT_EXT, dev), fmt | so.FMT_EXT, dev), so.quantize(x, k, fmt))
+    # misaligned device pointers take the scalar path
+    xd = torch.from_numpy(x).to(dev)
+    sl = xd[1:4098]
+    y = torch.empty(4100, device=dev)[3:]
+    y = y[:4097]
+    lib.check(lib.load().slfp_quantize_f32(sl.data_ptr(), y.data_ptr(), 4097, float(k), fmt, _stream()))
+    assert same_bits(y.cpu().numpy(), so.quantize(x[1:4098], k, fmt))
+    # empty input is a no-op
+    assert lib.load().slfp_quantize_f32(xd.data_ptr(), xd.data_ptr(), 0, 1.0, fmt, _stream()) == 0
+
+
+def test_quantizer_modules_bit_exact_and_ste(dev, codec_golden):
+    import utils.sfp_quant as sq
+    x = torch.from_numpy(codec_golden["act8_in_bits"].view(np.float32).copy()).to(dev)
+    for k, fa, fw in ((8, "act8", "w8"), (7, "act7", "w7")):
+        assert same_bits(sq.act_quantize_func(k)(x).cpu().numpy(), so.quantize(x.cpu().numpy(), 1.0, FMT[fa]))
+        assert same_bits(sq.weight_quantize_func(k)(x).cpu().numpy(), so.quantize(x.cpu().numpy(), 1.0, FMT[fw]))
+    z = torch.randn(1000, device=dev, requires_grad=True)
+    out = sq.quantize_act(8)(z)
+    out.backward(torch.ones_like(out) * 3)
+    assert torch.equal(z.grad, torch.full_like(z, 3.0))  # straight-through (utils/sfp_quant.py:99-102)
+    # channels_last views keep their layout
+    a = torch.randn(2, 8, 5, 5, device=dev).to(memory_format=torch.channels_last)
+    q = sq.quantize_act(8)(a)
+    assert q.is_contiguous(memory_format=torch.channels_last)
+    assert same_bits(q.cpu().numpy(), so.quantize(a.cpu().numpy(), 1.0, so.FMT_ACT8))
+
+
+# ------------------------------------------------------------------ conv: golden cases
+def _golden_case(conv_golden, key):
+    name, q = key.rsplit("_q", 1)
+    meta = [int(v) for v in conv_golden[name + "_meta"]]
+    Ka, Kw = conv_golden[name + "_scales"]
+    b = conv_golden[name + "_b"] if meta[9] else None
+    return name, int(q), meta, np.float64(Ka), np.float64(Kw), conv_golden[name + "_x"], conv_golden[name + "_w"], b
+
+
+def _build(cf, q, meta, Ka, Kw, w, b, dev):
+    N, C, H, W, O, k, s, p, g, has_b = meta
+    factory = cf.conv2d_Q_bias if has_b else cf.conv2d_Q
+    m = factory(q_bit=q, Kw=Kw, Ka=Ka)(C, O, k, Kw, Ka, s, p, groups=g, bias=bool(has_b)).eval().to(dev)
+    with torch.no_grad():
+        m.weight.copy_(torch.from_numpy(w))
+        if has_b:
+            m.bias.copy_(torch.from_numpy(b))
+    return m
+
+
+@pytest.mark.parametrize("layout", ["nchw", "channels_last"])
+@pytest.mark.parametrize("passes", [3, 1])
+def test_conv_golden_cases(lib, dev, conv_golden, layout, passes):
+    import utils.conv2d_func as cf
+    cf.options.mfma_passes = passes
+    try:
+        seen = set()
+        for key in [str(k) for k in conv_golden["case_keys"]]:
+            name, q, meta, Ka, Kw, x, w, b = _golden_case(conv_golden, key)
+            m = _build(cf, q, meta, Ka, Kw, w, b, dev)
+            xt = torch.from_numpy(x).to(dev)
+            if layout == "channels_last":
+                xt = xt.contiguous(memory_format=torch.channels_last)
+            with torch.no_grad():
+                y = m(xt)
+            ref = conv_golden[key + "_y"]
+            assert tuple(y.shape) == ref.shape, key
+            if layout == "channels_last":
+                assert y.is_contiguous(memory_format=torch.channels_last), key
+            else:
+                assert y.is_contiguous(), key
+            kern = m._last_kernel if q != 32 else "passthrough"
+            seen.add(kern)
+            tol = TOL_F16X1 if kern == "pw_mfma_f16x1" else TOL_EXACT
+            emax, el2 = rel_errors(y.cpu().numpy(), ref)
+            assert emax <= tol and el2 <= tol, (key, kern, emax, el2)
+            if q != 32:
+                # the stashed operands are the reference's self.input_q / self.weight_q, bit for bit
+                if key + "_xq" in conv_golden.files:
+                    assert same_bits(m.input_q.cpu().numpy(), conv_golden[key + "_xq"]), key
+                wq_ref = so.quantize(w, np.float32(Kw), so.FMT_W8 if q == 8 else so.FMT_SFP7)
+                assert same_bits(m.weight_q.cpu().numpy(), wq_ref), key
+                assert m.output is y
+        assert {"dw3x3_nhwc", "direct_nhwc", "pw_mfma_f16_exact", "passthrough"} <= seen
+        assert ("pw_mfma_f16x3" if passes == 3 else "pw_mfma_f16x1") in seen
+    finally:
+        cf.options.mfma_passes = 0
+
+
+def test_linear_golden(dev, conv_golden):
+    import utils.conv2d_func as cf
+    Ka, Kw = [np.float64(v) for v in conv_golden["linear_scales"]]
+    for q in (8, 7):
+        m = cf.linear_Q(q, Kw, Ka)(64, 10).eval().to(dev)
+        with torch.no_grad():
+            m.weight.copy_(torch.from_numpy(conv_golden["linear_w"]))
+            m.bias.copy_(torch.from_numpy(conv_golden["linear_b"]))
+            y = m(torch.from_numpy(conv_golden["linear_x"]).to(dev))
+        emax, el2 = rel_errors(y.cpu().numpy(), conv_golden[f"linear_q{q}_y"])
+        assert emax <= TOL_EXACT and el2 <= TOL_EXACT, (q, emax, el2)
+
+
+# ------------------------------------------------------------------ conv: MobileNetV1 layer shapes vs the oracle
+def _raw_conv(lib, dev, x_nhwc, w_oihw, bias, stride, pad, groups, Ka, Kw, qbits, passes=0):
+    """Straight through the C ABI (no torch module): NHWC in, NHWC out."""
+    L = lib.load()
+    N, H, W, C = x_nhwc.shape
+    O, Cg, KH, KW = w_oihw.shape
+    d = lib.ConvDesc(n=N, c_in=C, h=H, w=W, c_out=O, kh=KH, kw=KW, stride_h=stride, stride_w=stride, pad_h=pad, pad_w=pad,
+                     dil_h=1, dil_w=1, groups=groups, x_layout=lib.LAYOUT_NHWC, y_layout=lib.LAYOUT_NHWC, qbits=qbits,
+                     ka=float(np.float32(Ka)), kw_scale=float(np.float32(Kw)), mfma_passes=passes, reserved=0)
+    ho, wo = ctypes.c_int64(), ctypes.c_int64()
+    lib.check(L.slfp_conv2d_out_shape(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)))
+    blob = torch.empty(L.slfp_conv2d_wprep_bytes(ctypes.byref(d)), dtype=torch.uint8, device=dev)
+    lib.check(L.slfp_conv2d_prepare_weights(ctypes.byref(d), w_oihw.data_ptr(), blob.data_ptr(), None, _stream()))
+    y = torch.empty((N, ho.value, wo.value, O), dtype=torch.float32, device=dev)
+    lib.check(L.slfp_conv2d_fwd(ctypes.byref(d), x_nhwc.data_ptr(), blob.data_ptr(),
+                                bias.data_ptr() if bias is not None else None, y.data_ptr(), None, None, _stream()))
+    return y, L.slfp_conv2d_kernel_name(ctypes.byref(d)).decode()
+
+
+def _check_against_oracle(lib, dev, N, C, H, O, k, s, p, g, qbits, passes, seed, images=None, bias=False):
+    """Run the HIP conv on a seeded [N,H,H,C] input; compare images `images` (default all)
+    against the CPU oracle run on those images alone (images are independent units)."""
+    Ka, Kw = 2.6023073196411133 / 15.5, 1.9635683298110962 / 15.5
+    gen = torch.Generator(device="cpu").manual_seed(seed)
+    w = (torch.randn((O, C // g, k, k), generator=gen) * (5.0 * Kw)).to(dev)
+    b = (torch.randn(O, generator=gen) * 0.5).to(dev) if bias else None
+    ggen = torch.Generator(device=dev).manual_seed(seed)
+    x = torch.randn((N, H, H, C), generator=ggen, device=dev) * (6.0 * Ka)
+    x = torch.relu(x) if C > 3 else x  # post-ReLU-like except for the image stem
+    y, kern = _raw_conv(lib, dev, x, w, b, s, p, g, Ka, Kw, qbits, passes)
+    idx = list(range(N)) if images is None else images
+    xs = x[idx].permute(0, 3, 1, 2).contiguous().cpu().numpy()
+    ref = so.conv2d(xs, w.cpu().numpy(), None if b is None else b.cpu().numpy(), s, p, 1, g, Ka, Kw, qbits)
+    got = y[idx].permute(0, 3, 1, 2).contiguous().cpu().numpy()
+    tol = TOL_F16X1 if kern == "pw_mfma_f16x1" else TOL_EXACT
+    emax, el2 = rel_errors(got, ref)
+    assert emax <= tol and el2 <= tol, (kern, (N, C, H, O, k, s), emax, el2)
+    return kern, emax, el2
+
+
+# (C_in, H_in, C_out, k, stride, pad, groups): nets_imgnet/mobilenetv1.py:43-57
+MBV1 = [(3, 224, 32, 3, 2, 1, 1),
+        (32, 112, 32, 3, 1, 1, 32), (32, 112, 64, 1, 1, 0, 1),
+        (64, 112, 64, 3, 2, 1, 64), (64, 56, 128, 1, 1, 0, 1),
+        (128, 56, 128, 3, 1, 1, 128), (128, 56, 128, 1, 1, 0, 1),
+        (128, 56, 128, 3, 2, 1, 128), (128, 28, 256, 1, 1, 0, 1),
+        (256, 28, 256, 3, 1, 1, 256), (256, 28, 256, 1, 1, 0, 1),
+        (256, 28, 256, 3, 2, 1, 256), (256, 14, 512, 1, 1, 0, 1),
+        (512, 14, 512, 3, 1, 1, 512), (512, 14, 512, 1, 1, 0, 1),
+        (512, 14, 512, 3, 2, 1, 512), (512, 7, 1024, 1, 1, 0, 1),
+        (1024, 7, 1024, 3, 1, 1, 1024), (1024, 7, 1024, 1, 1, 0, 1)]
+
+
+@pytest.mark.parametrize("qbits, passes", [(8, 3), (8, 1), (7, 0)])
+def test_mobilenetv1_layer_shapes_vs_oracle(lib, dev, qbits, passes):
+    kerns = set()
+    for i, (C, H, O, k, s, p, g) in enumerate(MBV1):
+        kern, emax, el2 = _check_against_oracle(lib, dev, 2, C, H, O, k, s, p, g, qbits, passes, seed=100 + i)
+        kerns.add(kern)
+    assert "dw3x3_nhwc" in kerns and "direct_nhwc" in kerns and any(k.startswith("pw_mfma") for k in kerns)
+
+
+def test_other_net_shapes_vs_oracle(lib, dev):
+    # ResNet-50 strided 1x1 downsample + 7x7 stem, SqueezeNet 7x7 s2 p0 + bias, VGG 3x3 + bias,
+    # ShuffleNetV2 odd widths (24/58/116), AlexNet 11x11 s4 p2
+    cases = [(64, 56, 256, 1, 1, 0, 1, False), (256, 56, 512, 1, 2, 0, 1, False), (3, 64, 64, 7, 2, 3, 1, False),
+             (3, 63, 96, 7, 2, 0, 1, True), (64, 28, 128, 3, 1, 1, 1, True), (24, 28, 58, 1, 1, 0, 1, False),
+             (58, 28, 58, 3, 2, 1, 58, False), (116, 14, 116, 3, 1, 1, 116, False), (116, 14, 116, 1, 1, 0, 1, False),
+             (3, 67, 64, 11, 4, 2, 1, True), (96, 13, 16, 1, 1, 0, 1, True), (16, 13, 64, 3, 1, 1, 1, True)]
+    for i, (C, H, O, k, s, p, g, bias) in enumerate(cases):
+        for qbits in (8, 7):
+            _check_against_oracle(lib, dev, 2, C, H, O, k, s, p, g, qbits, 3, seed=300 + i, bias=bias)
+
+
+# ------------------------------------------------------------------ BASELINE full size (batch 256)
+@pytest.mark.parametrize("layer", [0, 1, 2, 3, 6, 14, 17, 18])
+def test_full_batch_256_sampled_images(lib, dev, layer):
+    """At BASELINE.json's full size (batch 256, 224x224 ImageNet shapes) the oracle cannot
+    run the whole tensor in seconds; images are independent units through the whole path,
+    so three sampled images of the full-batch run are checked against the oracle."""
+    C, H, O, k, s, p, g = MBV1[layer]
+    _check_against_oracle(lib, dev, 256, C, H, O, k, s, p, g, 8, 3, seed=500 + layer, images=[0, 131, 255])
+    _check_against_oracle(lib, dev, 256, C, H, O, k, s, p, g, 8, 1, seed=600 + layer, images=[7, 255])
+
+
+def test_batch_order_independence(lib, dev):
+    """Size-independent property: permuting the images permutes the outputs, bit for bit."""
+    Ka, Kw = 0.17, 0.12
+    g = torch.Generator(device=dev).manual_seed(3)
+    for (C, O, k, s, p, grp) in [(64, 64, 3, 2, 1, 64), (128, 256, 1, 1, 0, 1), (3, 32, 3, 2, 1, 1)]:
+        x = torch.relu(torch.randn((16, 28, 28, C), generator=g, device=dev))
+        w = torch.randn((O, C // grp, k, k), generator=g, device=dev) * 0.5
+        perm = torch.randperm(16, device=dev)
+        y1, _ = _raw_conv(lib, dev, x, w, None, s, p, grp, Ka, Kw, 8)
+        y2, _ = _raw_conv(lib, dev, x[perm].contiguous(), w, None, s, p, grp, Ka, Kw, 8)
+        assert torch.equal(y1[perm], y2)
+
+
+# ------------------------------------------------------------------ module behaviour on the GPU
+def test_weight_cache_invalidation_and_autograd(dev):
+    import utils.conv2d_func as cf
+    Ka, Kw = np.float64(0.17), np.float64(0.12)
+    m = cf.conv2d_Q(8, Kw, Ka)(16, 32, 3, Kw, Ka, 1, 1).to(dev)
+    x = torch.relu(torch.randn(2, 16, 9, 9, device=dev))
+    # the reference's eval loop runs WITHOUT no_grad and with weight.requires_grad (imgnet_train_eval.py:177-196)
+    y0 = m(x)
+    assert y0.requires_grad and m._last_kernel == "direct_nhwc"
+    ref, _, _ = tp.conv2d_q(x, m.weight, None, 1, 1, 1, 1, Ka, Kw, 8)  # the torch port runs on the GPU too
+    assert rel_errors(y0.detach().cpu().numpy(), ref.detach().cpu().numpy())[0] < TOL_EXACT
+    # straight-through gradients match the reference composite
+    x1 = x.clone().requires_grad_(True)
+    (m(x1) * 1.0).sum().backward()
+    gw = m.weight.grad.clone()
+    m.weight.grad = None
+    x2 = x.clone().requires_grad_(True)
+    with torch.no_grad():
+        _, xq, wq = tp.conv2d_q(x, m.weight, None, 1, 1, 1, 1, Ka, Kw, 8)
+    ka32, kw32 = float(np.float32(Ka)), float(np.float32(Kw))
+    xs, ws = x2 / ka32, m.weight / kw32
+    # straight-through estimator written with the detach trick (independent of the module's backward)
+    r2 = torch.nn.functional.conv2d(xs + (xq - xs).detach(), ws + (wq - ws).detach(), None, 1, 1) * ka32 * kw32
+    r2.sum().backward()
+    assert torch.allclose(x1.grad, x2.grad, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(gw, m.weight.grad, rtol=1e-4, atol=1e-4)
+    # in-place weight update -> the prepared blob is rebuilt (the reference re-quantizes every call)
+    with torch.no_grad():
+        m.weight.mul_(0.5)
+        y1 = m(x)
+        ref1, _, _ = tp.conv2d_q(x, m.weight, None, 1, 1, 1, 1, Ka, Kw, 8)
+    assert rel_errors(y1.cpu().numpy(), ref1.cpu().numpy())[0] < TOL_EXACT
+    assert not torch.allclose(y1, y0.detach())
+    # shape errors surface as RuntimeError, like F.conv2d
+    with pytest.raises(RuntimeError):
+        m(torch.randn(2, 8, 9, 9, device=dev))
+
+
+def test_transposes_roundtrip(lib, dev):
+    L = lib.load()
+    x = torch.randn(3, 37, 11, 13, device=dev)
+    y = torch.empty(3, 11, 13, 37, device=dev)
+    lib.check(L.slfp_nchw_to_nhwc_f32(x.data_ptr(), y.data_ptr(), 3, 37, 11, 13, _stream()))
+    assert torch.equal(y, x.permute(0, 2, 3, 1).contiguous())
+    z = torch.empty_like(x)
+    lib.check(L.slfp_nhwc_to_nchw_f32(y.data_ptr(), z.data_ptr(), 3, 37, 11, 13, _stream()))
+    assert torch.equal(z, x)
