@@ -22,7 +22,7 @@ SYMBOLS = (
     "slfp_conv2d_out_shape", "slfp_conv2d_kernel_name", "slfp_conv2d_wprep_bytes",
     "slfp_conv2d_prepare_weights", "slfp_conv2d_workspace_bytes", "slfp_conv2d_fwd",
     "slfp_linear_workspace_bytes", "slfp_linear_fwd",
-    "slfp_nchw_to_nhwc_f32", "slfp_nhwc_to_nchw_f32",
+    "slfp_nchw_to_nhwc_f32", "slfp_nhwc_to_nchw_f32", "slfp_debug_div_mismatches",
 )
 
 
@@ -77,6 +77,7 @@ def load():
         "slfp_linear_fwd": (ci, [vp, vp, vp, vp, i64, i64, i64, cf, cf, ci, ci, vp, vp]),
         "slfp_nchw_to_nhwc_f32": (ci, [vp, vp, i64, i64, i64, i64, vp]),
         "slfp_nhwc_to_nchw_f32": (ci, [vp, vp, i64, i64, i64, i64, vp]),
+        "slfp_debug_div_mismatches": (ci, [cf, vp, vp]),
     }
     assert set(sigs) == set(SYMBOLS)
     for name, (res, args) in sigs.items():

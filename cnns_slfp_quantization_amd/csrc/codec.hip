@@ -40,36 +40,37 @@ constexpr int kThreads = 256;
 // MODE 0: y = Q(x/scale) float32; MODE 1: code byte.
 template <int FMT, int MODE>
 __global__ __launch_bounds__(kThreads) void k_codec(const float* __restrict__ x, void* __restrict__ out,
-                                                    size_t n, float scale, int ext, int vec_ok) {
+                                                    size_t n, const ScaleDiv sd, int ext, int vec_ok) {
     __shared__ uint32_t sT[16];
-    lut_fill(sT);
+    lut_fill<FMT>(sT);
     __syncthreads();
     const size_t nvec = vec_ok ? n / 4 : 0;
     const size_t stride = (size_t)gridDim.x * kThreads;
     for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += stride) {
         const float4 v = reinterpret_cast<const float4*>(x)[i];
-        const uint32_t u0 = __float_as_uint(v.x / scale), u1 = __float_as_uint(v.y / scale);
-        const uint32_t u2 = __float_as_uint(v.z / scale), u3 = __float_as_uint(v.w / scale);
+        const uint32_t u0 = __float_as_uint(div_const(v.x, sd)), u1 = __float_as_uint(div_const(v.y, sd));
+        const uint32_t u2 = __float_as_uint(div_const(v.z, sd)), u3 = __float_as_uint(div_const(v.w, sd));
         if constexpr (MODE == 0) {
             float4 r;
-            r.x = __uint_as_float(quant_bits<FMT>(u0, sT));
-            r.y = __uint_as_float(quant_bits<FMT>(u1, sT));
-            r.z = __uint_as_float(quant_bits<FMT>(u2, sT));
-            r.w = __uint_as_float(quant_bits<FMT>(u3, sT));
+            r.x = __uint_as_float(quant_bits<FMT>(u0, __float_as_uint(v.x), sT));
+            r.y = __uint_as_float(quant_bits<FMT>(u1, __float_as_uint(v.y), sT));
+            r.z = __uint_as_float(quant_bits<FMT>(u2, __float_as_uint(v.z), sT));
+            r.w = __uint_as_float(quant_bits<FMT>(u3, __float_as_uint(v.w), sT));
             reinterpret_cast<float4*>(out)[i] = r;
         } else {
-            const uint32_t c = quant_code<FMT>(u0, ext) | (quant_code<FMT>(u1, ext) << 8) |
-                               (quant_code<FMT>(u2, ext) << 16) | (quant_code<FMT>(u3, ext) << 24);
+            const uint32_t c = quant_code<FMT>(u0, __float_as_uint(v.x), ext) | (quant_code<FMT>(u1, __float_as_uint(v.y), ext) << 8) |
+                               (quant_code<FMT>(u2, __float_as_uint(v.z), ext) << 16) | (quant_code<FMT>(u3, __float_as_uint(v.w), ext) << 24);
             reinterpret_cast<uint32_t*>(out)[i] = c;
         }
     }
     // scalar tail (and the whole array when a pointer is not 16-byte aligned)
     for (size_t i = nvec * 4 + (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
-        const uint32_t u = __float_as_uint(x[i] / scale);
+        const float xi = x[i];
+        const uint32_t u = __float_as_uint(div_const(xi, sd));
         if constexpr (MODE == 0) {
-            reinterpret_cast<float*>(out)[i] = __uint_as_float(quant_bits<FMT>(u, sT));
+            reinterpret_cast<float*>(out)[i] = __uint_as_float(quant_bits<FMT>(u, __float_as_uint(xi), sT));
         } else {
-            reinterpret_cast<uint8_t*>(out)[i] = (uint8_t)quant_code<FMT>(u, ext);
+            reinterpret_cast<uint8_t*>(out)[i] = (uint8_t)quant_code<FMT>(u, __float_as_uint(xi), ext);
         }
     }
 }
@@ -78,7 +79,7 @@ template <int FMT>
 __global__ __launch_bounds__(kThreads) void k_decode(const uint8_t* __restrict__ code, float* __restrict__ y,
                                                      size_t n, int ext, int vec_ok) {
     __shared__ uint32_t sT[16];
-    lut_fill(sT);
+    lut_fill<kFmtW8>(sT);  // identity table: decode indexes it with the log code
     __syncthreads();
     const size_t nvec = vec_ok ? n / 4 : 0;
     const size_t stride = (size_t)gridDim.x * kThreads;
@@ -107,10 +108,11 @@ static int launch_codec(const float* x, void* out, size_t n, float scale, int fm
     const int f = fmt & kFmtMask, ext = (fmt & kFmtExt) ? 1 : 0;
     const int vec_ok = aligned16(x) && ((reinterpret_cast<uintptr_t>(out) & (MODE == 0 ? 15u : 3u)) == 0);
     const int g = grid_for(n);
+    const ScaleDiv sd = make_scale_div(scale);
     switch (f) {
-        case kFmtAct8: hipLaunchKernelGGL((k_codec<kFmtAct8, MODE>), dim3(g), dim3(kThreads), 0, st, x, out, n, scale, ext, vec_ok); break;
-        case kFmtW8: hipLaunchKernelGGL((k_codec<kFmtW8, MODE>), dim3(g), dim3(kThreads), 0, st, x, out, n, scale, ext, vec_ok); break;
-        case kFmtSfp7: hipLaunchKernelGGL((k_codec<kFmtSfp7, MODE>), dim3(g), dim3(kThreads), 0, st, x, out, n, scale, ext, vec_ok); break;
+        case kFmtAct8: hipLaunchKernelGGL((k_codec<kFmtAct8, MODE>), dim3(g), dim3(kThreads), 0, st, x, out, n, sd, ext, vec_ok); break;
+        case kFmtW8: hipLaunchKernelGGL((k_codec<kFmtW8, MODE>), dim3(g), dim3(kThreads), 0, st, x, out, n, sd, ext, vec_ok); break;
+        case kFmtSfp7: hipLaunchKernelGGL((k_codec<kFmtSfp7, MODE>), dim3(g), dim3(kThreads), 0, st, x, out, n, sd, ext, vec_ok); break;
         default: return fail(SLFP_ERR_BAD_ARG, "unknown codec format %d", fmt);
     }
     return check_launch("slfp codec kernel");
@@ -140,6 +142,34 @@ __global__ __launch_bounds__(256) void k_transpose(const float* __restrict__ x, 
     }
 }
 
+// Exhaustive self-check of div_const against IEEE `/` over ALL 2^32 float32 patterns:
+// out[0] = #x with |x| and |x/d| both within [1e-20, 1e20] (no residual underflow) whose quotient differs bitwise,
+// out[1] = #x for which ANY of the three quantizers would return a different value.
+__global__ __launch_bounds__(kThreads) void k_div_check(const ScaleDiv sd, unsigned long long* __restrict__ out) {
+    __shared__ uint32_t sA[16], sW[16];
+    lut_fill<kFmtAct8>(sA);
+    lut_fill<kFmtW8>(sW);
+    __syncthreads();
+    unsigned long long bad_q = 0, bad_code = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * kThreads;
+    for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < (1ull << 32); i += stride) {
+        const float x = __uint_as_float((uint32_t)i);
+        const float ref = x / sd.d;
+        const float got = div_const(x, sd);
+        const uint32_t ur = __float_as_uint(ref), ug = __float_as_uint(got);
+        const float mag = fabsf(ref);
+        const float mx = fabsf(x);
+        if (mag >= 1e-20f && mag <= 1e20f && mx >= 1e-20f && mx <= 1e20f && ur != ug) ++bad_q;
+        const uint32_t ux = (uint32_t)i;
+        if (quant_bits<kFmtAct8>(ur, ux, sA) != quant_bits<kFmtAct8>(ug, ux, sA)) ++bad_code;
+        if (quant_bits<kFmtW8>(ur, ux, sW) != quant_bits<kFmtW8>(ug, ux, sW)) ++bad_code;
+        if (quant_bits<kFmtSfp7>(ur, ux, sW) != quant_bits<kFmtSfp7>(ug, ux, sW)) ++bad_code;
+        if (quant_bits<kFmtAct8, 4>(__float_as_uint(ref * 16.f), ux, sA) != quant_bits<kFmtAct8, 4>(__float_as_uint(got * 16.f), ux, sA)) ++bad_code;
+    }
+    if (bad_q) atomicAdd(out, bad_q);
+    if (bad_code) atomicAdd(out + 1, bad_code);
+}
+
 static int launch_transpose(const float* x, float* y, int64_t n, int64_t rows, int64_t cols, hipStream_t st) {
     if (!x || !y || n <= 0 || rows <= 0 || cols <= 0) return fail(SLFP_ERR_BAD_ARG, "transpose: bad argument");
     if (n > 65535 || ceil_div(rows, 32) > 65535) return fail(SLFP_ERR_UNSUPPORTED, "transpose: grid too large");
@@ -167,6 +197,7 @@ int slfp_encode_f32(const float* x, uint8_t* code, size_t n, float scale_div, in
     if (n == 0) return SLFP_OK;
     if (!x || !code) return fail(SLFP_ERR_BAD_ARG, "slfp_encode_f32: null pointer");
     if (!(scale_div > 0.f)) return fail(SLFP_ERR_BAD_ARG, "slfp_encode_f32: scale must be > 0");
+    if (!scale_div_ok(scale_div)) return fail(SLFP_ERR_UNSUPPORTED, "slfp_encode_f32: scale must be within [1e-30, 1e30]");
     return launch_codec<1>(x, code, n, scale_div, fmt, as_stream(stream));
 }
 
@@ -174,6 +205,7 @@ int slfp_quantize_f32(const float* x, float* y, size_t n, float scale_div, int f
     if (n == 0) return SLFP_OK;
     if (!x || !y) return fail(SLFP_ERR_BAD_ARG, "slfp_quantize_f32: null pointer");
     if (!(scale_div > 0.f)) return fail(SLFP_ERR_BAD_ARG, "slfp_quantize_f32: scale must be > 0");
+    if (!scale_div_ok(scale_div)) return fail(SLFP_ERR_UNSUPPORTED, "slfp_quantize_f32: scale must be within [1e-30, 1e30]");
     return launch_codec<0>(x, y, n, scale_div, fmt, as_stream(stream));
 }
 
@@ -188,6 +220,16 @@ int slfp_decode_f32(const uint8_t* code, float* y, size_t n, int fmt, void* stre
     else if (f == kFmtAct8 || f == kFmtW8) hipLaunchKernelGGL((k_decode<kFmtAct8>), dim3(g), dim3(kThreads), 0, st, code, y, n, ext, vec_ok);
     else return fail(SLFP_ERR_BAD_ARG, "unknown codec format %d", fmt);
     return check_launch("slfp decode kernel");
+}
+
+int slfp_debug_div_mismatches(float scale_div, unsigned long long* out2, void* stream) {
+    if (!out2 || !(scale_div > 0.f)) return fail(SLFP_ERR_BAD_ARG, "slfp_debug_div_mismatches: bad argument");
+    hipStream_t st = as_stream(stream);
+    if (hipMemsetAsync(out2, 0, 2 * sizeof(unsigned long long), st) != hipSuccess) return check_launch("hipMemsetAsync");
+    if (!scale_div_ok(scale_div)) return fail(SLFP_ERR_UNSUPPORTED, "scale must be within [1e-30, 1e30]");
+    ScaleDiv sd = make_scale_div(scale_div);
+    hipLaunchKernelGGL(k_div_check, dim3(256 * 16), dim3(kThreads), 0, st, sd, out2);
+    return check_launch("slfp division self-check kernel");
 }
 
 int slfp_nchw_to_nhwc_f32(const float* x, float* y, int64_t n, int64_t c, int64_t h, int64_t w, void* stream) {

@@ -23,6 +23,8 @@ int make_plan(const slfp_conv2d_desc* d, ConvPlan* plan) {
         (d->y_layout != SLFP_LAYOUT_NCHW && d->y_layout != SLFP_LAYOUT_NHWC))
         return fail(SLFP_ERR_BAD_ARG, "conv2d: unknown layout");
     if (!(d->ka > 0.f) || !(d->kw_scale > 0.f)) return fail(SLFP_ERR_BAD_ARG, "conv2d: Ka and Kw must be > 0");
+    if (!scale_div_ok(d->ka) || !scale_div_ok(d->kw_scale))
+        return fail(SLFP_ERR_UNSUPPORTED, "conv2d: Ka and Kw must be within [1e-30, 1e30]");
     if (d->mfma_passes != SLFP_MFMA_DEFAULT && d->mfma_passes != SLFP_MFMA_F16X1 && d->mfma_passes != SLFP_MFMA_F16X3)
         return fail(SLFP_ERR_BAD_ARG, "conv2d: mfma_passes must be 0, 1 or 3");
     const int64_t eh = d->h + 2 * (int64_t)d->pad_h - (int64_t)d->dil_h * (d->kh - 1) - 1;
@@ -34,7 +36,7 @@ int make_plan(const slfp_conv2d_desc* d, ConvPlan* plan) {
         return fail(SLFP_ERR_UNSUPPORTED, "conv2d: dimension exceeds 2^31");
     plan->fmt_act = d->qbits == 8 ? kFmtAct8 : kFmtSfp7;
     plan->fmt_w = d->qbits == 8 ? kFmtW8 : kFmtSfp7;
-    plan->passes = d->qbits == 7 ? 1 : (d->mfma_passes == SLFP_MFMA_F16X1 ? 1 : 3);
+    plan->passes = d->qbits == 7 ? 1 : (d->mfma_passes == SLFP_MFMA_F16X3 ? 3 : 1);
     plan->k_pad = plan->n_pad = 0;
     plan->s1 = d->ka;
     plan->s2 = d->kw_scale;
@@ -63,13 +65,13 @@ int make_plan(const slfp_conv2d_desc* d, ConvPlan* plan) {
 template <int FMT>
 __global__ __launch_bounds__(256) void k_prepare(const float* __restrict__ w, void* __restrict__ prep,
                                                  float* __restrict__ wq_oihw, int64_t total, int O, int Cg, int KH,
-                                                 int KW, float kw_scale, int family, int KS, int64_t plane) {
+                                                 int KW, const ScaleDiv sd, int family, int KS, int64_t plane) {
     __shared__ uint32_t sT[16];
-    lut_fill(sT);
+    lut_fill<FMT>(sT);
     __syncthreads();
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
-    const float q = quantize_scaled<FMT>(w[idx], kw_scale, sT);
+    const float q = quantize_scaled<FMT>(w[idx], sd, sT);
     if (wq_oihw) wq_oihw[idx] = q;
     int64_t r = idx;
     const int kw = (int)(r % KW); r /= KW;
@@ -81,8 +83,10 @@ __global__ __launch_bounds__(256) void k_prepare(const float* __restrict__ w, vo
     } else if (family == kDirect) {
         reinterpret_cast<float*>(prep)[((size_t)(kh * KW + kw) * Cg + ci) * O + o] = q;  // [KH][KW][Cg][O]
     } else {
-        // MFMA 16x16x32 A-fragment order: tile (o/16, k/32), lane = ((k%32)/8)*16 + o%16, elem k%8
-        const int nt = o >> 4, row = o & 15, ks = ci >> 5, kq = (ci & 31) >> 3, j = ci & 7;
+        // MFMA 16x16x32 A-fragment order: tile (o/16, k/32), lane = kq*16 + o%16 where lane-quarter kq
+        // holds k%32 in {kq*4..kq*4+3} (elements 0-3) and {16+kq*4..16+kq*4+3} (elements 4-7): conv_pw.hip
+        const int nt = o >> 4, row = o & 15, ks = ci >> 5, kk = ci & 31;
+        const int kq = (kk & 15) >> 2, j = (kk >> 4) * 4 + (kk & 3);
         const size_t at = (((size_t)nt * KS + ks) * 64 + (size_t)(kq * 16 + row)) * 8 + j;
         const float v = 16.0f * q;  // 2^4 pre-scale (exact), see conv_pw.hip
         const _Float16 hi = (_Float16)v;
@@ -102,12 +106,13 @@ int launch_prepare_weights(const slfp_conv2d_desc& d, const ConvPlan& p, const f
     const int64_t plane = p.k_pad * p.n_pad;
     const int KS = (int)(p.k_pad / 32);
     const unsigned grid = (unsigned)ceil_div(total, 256);
+    const ScaleDiv sd = make_scale_div(d.kw_scale);
     if (p.fmt_w == kFmtW8)
         hipLaunchKernelGGL((k_prepare<kFmtW8>), dim3(grid), dim3(256), 0, stream, w_oihw, wprep, weight_q_oihw, total,
-                           (int)d.c_out, Cg, (int)d.kh, (int)d.kw, d.kw_scale, (int)p.family, KS, plane);
+                           (int)d.c_out, Cg, (int)d.kh, (int)d.kw, sd, (int)p.family, KS, plane);
     else
         hipLaunchKernelGGL((k_prepare<kFmtSfp7>), dim3(grid), dim3(256), 0, stream, w_oihw, wprep, weight_q_oihw, total,
-                           (int)d.c_out, Cg, (int)d.kh, (int)d.kw, d.kw_scale, (int)p.family, KS, plane);
+                           (int)d.c_out, Cg, (int)d.kh, (int)d.kw, sd, (int)p.family, KS, plane);
     return check_launch("slfp weight prepare kernel");
 }
 

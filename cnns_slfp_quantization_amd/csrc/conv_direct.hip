@@ -22,7 +22,8 @@ struct DirParams {
     int groups, Cg, Og, Ho, Wo;
     int tiles_h, tiles_w, oc_chunks;
     int CC, IH, IW;
-    float ka, s1, s2;
+    ScaleDiv sd;
+    float s1, s2;
     uint32_t nblocks;
 };
 
@@ -33,7 +34,7 @@ __global__ __launch_bounds__(kDirThreads) void k_direct(const float* __restrict_
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* sT = reinterpret_cast<uint32_t*>(smem);
     float* tile = reinterpret_cast<float*>(smem + 64);  // [IH][IW][CC]
-    lut_fill(sT);
+    lut_fill<FMT>(sT);
 
     uint32_t b = xcd_remap(blockIdx.x, p.nblocks);
     const int oc = b % p.oc_chunks; b /= p.oc_chunks;
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(kDirThreads) void k_direct(const float* __restrict_
             float v = 0.f;
             if (gh >= 0 && gh < p.H && gw >= 0 && gw < p.W) {
                 const float raw = x[(((size_t)n * p.H + gh) * p.W + gw) * p.C + g * p.Cg + cc0 + c];
-                v = quantize_scaled<FMT>(raw, p.ka, sT);
+                v = quantize_scaled<FMT>(raw, p.sd, sT);
             }
             tile[(ih * p.IW + iw) * p.CC + c] = v;
         }
@@ -148,7 +149,7 @@ int launch_direct(const slfp_conv2d_desc& d, const ConvPlan& plan, const float* 
     if (cc > 32) cc = 32;
     if (cc > p.Cg) cc = p.Cg;
     p.CC = cc;
-    p.ka = d.ka; p.s1 = plan.s1; p.s2 = plan.s2;
+    p.sd = make_scale_div(d.ka); p.s1 = plan.s1; p.s2 = plan.s2;
     const int64_t nblocks = (int64_t)p.N * p.tiles_h * p.tiles_w * p.groups * p.oc_chunks;
     if (nblocks > 0x7FFFFFFF) return fail(SLFP_ERR_UNSUPPORTED, "direct conv: grid too large");
     p.nblocks = (uint32_t)nblocks;

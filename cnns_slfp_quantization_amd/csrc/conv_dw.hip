@@ -14,6 +14,8 @@
 //     reference's two roundings, and stores 16 bytes.
 // For stride 2 the tile's columns are stored de-interleaved (even columns, then odd) so
 // that the 8 pixels a wave reads for one tap are contiguous in LDS (no bank conflicts).
+// rocprof (profiles/r01a) showed HBM traffic already ideal (halo re-reads hit L2) and the
+// kernel VALU-bound, so all index arithmetic is incremental (no runtime div/mod in loops).
 #include "slfp_device.hpp"
 #include "slfp_host.hpp"
 
@@ -24,9 +26,12 @@ constexpr int kDwThreads = 256;
 struct DwParams {
     int N, H, W, C, Ho, Wo;
     int TH, TW, tiles_h, tiles_w;
-    int CB, cgroups;   // channels per block (multiple of 4, CB/4 divides 256), #channel groups
+    int CB, cb4_shift, cgroups;  // channels per block (4 << cb4_shift), #channel groups
     int pad;
-    int IH, IW, IWh;   // input tile extent; IWh = (IW+1)/2 (stride-2 de-interleave)
+    int IH, IW, IWh;             // input tile extent; IWh = (IW+1)/2 (stride-2 de-interleave)
+    int in_step_h, in_step_w;    // (256 >> cb4_shift) pixels = in_step_h rows + in_step_w cols of the input tile
+    int out_step_h, out_step_w;  // same for the output tile
+    ScaleDiv sd;
     float ka, kw;
     uint32_t nblocks;
 };
@@ -38,7 +43,7 @@ __global__ __launch_bounds__(kDwThreads) void k_dw3x3(const float* __restrict__ 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* sT = reinterpret_cast<uint32_t*>(smem);      // 16 dwords
     float* tile = reinterpret_cast<float*>(smem + 64);     // [IH][IW][CB]
-    lut_fill(sT);
+    lut_fill<FMT>(sT);
 
     // logical block id -> (channel group, tile_w, tile_h, image); XCD-contiguous so that
     // tiles sharing a halo are served by the same L2.
@@ -48,53 +53,57 @@ __global__ __launch_bounds__(kDwThreads) void k_dw3x3(const float* __restrict__ 
     const int th = b % p.tiles_h; b /= p.tiles_h;
     const int n = b;
 
-    const int cb4 = p.CB >> 2;
-    const int c0 = cg * p.CB;
+    const int cb4 = 1 << p.cb4_shift;
+    const int my_c4 = threadIdx.x & (cb4 - 1);  // constant per thread: cb4 divides the block size
+    const int my_c = cg * p.CB + my_c4 * 4;
+    const bool c_live = my_c < p.C;
+    const int pix0 = threadIdx.x >> p.cb4_shift;
     const int h_in0 = th * p.TH * S - p.pad, w_in0 = tw * p.TW * S - p.pad;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
 
     // ---------------- LOAD + ENCODE phase ----------------
-    const int n_in = p.IH * p.IW * cb4;
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    constexpr int U = 4;  // loads kept in flight per thread
-    for (int base = threadIdx.x; base < n_in; base += kDwThreads * U) {
-        float4 v[U];
-        int dst[U];
-        bool live[U];
+    {
+        const int n_pix = p.IH * p.IW;
+        const int dp = kDwThreads >> p.cb4_shift;  // pixels between two items of a thread
+        int pix = pix0;
+        int ih = pix0 / p.IW, iw = pix0 - ih * p.IW;  // the only division: once per thread
+        const float* xn = x + (size_t)n * p.H * p.W * p.C + my_c;
+        constexpr int U = 4;  // loads kept in flight per thread
+        while (pix < n_pix) {
+            float4 v[U];
+            int dst[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int item = base + u * kDwThreads;
-            const int c4 = item % cb4;
-            const int pix = item / cb4;
-            const int iw = pix % p.IW, ih = pix / p.IW;
-            const int gh = h_in0 + ih, gw = w_in0 + iw, c = c0 + c4 * 4;
-            live[u] = item < n_in;
-            const bool inb = live[u] && gh >= 0 && gh < p.H && gw >= 0 && gw < p.W && c < p.C;
-            const int slot = (S == 2) ? ((iw & 1) * p.IWh + (iw >> 1)) : iw;
-            dst[u] = (ih * p.IW + slot) * p.CB + c4 * 4;
-            v[u] = zero4;
-            if (inb) v[u] = *reinterpret_cast<const float4*>(x + ((((size_t)n * p.H + gh) * p.W + gw) * p.C + c));
-        }
+            for (int u = 0; u < U; ++u) {
+                const int gh = h_in0 + ih, gw = w_in0 + iw;
+                const bool inb = pix < n_pix && c_live && gh >= 0 && gh < p.H && gw >= 0 && gw < p.W;
+                const int slot = (S == 2) ? ((iw & 1) * p.IWh + (iw >> 1)) : iw;
+                dst[u] = pix < n_pix ? (ih * p.IW + slot) * p.CB + my_c4 * 4 : -1;
+                v[u] = zero4;
+                if (inb) v[u] = *reinterpret_cast<const float4*>(xn + ((size_t)gh * p.W + gw) * p.C);
+                pix += dp;
+                ih += p.in_step_h;
+                iw += p.in_step_w;
+                if (iw >= p.IW) { iw -= p.IW; ++ih; }
+            }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (!live[u]) continue;
-            float4 q;
-            // Q(0/Ka) == 0, so padded / out-of-range zeros go through the same path.
-            q.x = quantize_scaled<FMT>(v[u].x, p.ka, sT);
-            q.y = quantize_scaled<FMT>(v[u].y, p.ka, sT);
-            q.z = quantize_scaled<FMT>(v[u].z, p.ka, sT);
-            q.w = quantize_scaled<FMT>(v[u].w, p.ka, sT);
-            *reinterpret_cast<float4*>(tile + dst[u]) = q;
+            for (int u = 0; u < U; ++u) {
+                if (dst[u] < 0) continue;
+                float4 q;
+                // Q(0/Ka) == 0, so padded / out-of-range zeros go through the same path.
+                q.x = quantize_scaled<FMT>(v[u].x, p.sd, sT);
+                q.y = quantize_scaled<FMT>(v[u].y, p.sd, sT);
+                q.z = quantize_scaled<FMT>(v[u].z, p.sd, sT);
+                q.w = quantize_scaled<FMT>(v[u].w, p.sd, sT);
+                *reinterpret_cast<float4*>(tile + dst[u]) = q;
+            }
         }
     }
 
-    // this thread's 4 channels x 9 taps (c4 is the same for every item of a thread
-    // because cb4 divides the block size)
-    const int my_c4 = threadIdx.x % cb4;
-    const int my_c = c0 + my_c4 * 4;
+    // this thread's 4 channels x 9 taps
     float4 wt[9];
     float4 bq = zero4;
-    if (my_c < p.C) {
+    if (c_live) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const float4*>(wq + (size_t)t * p.C + my_c);
         if (bias) {  // bias_q = bias / Ka / Kw (utils/conv2d_func.py:44)
@@ -108,34 +117,42 @@ __global__ __launch_bounds__(kDwThreads) void k_dw3x3(const float* __restrict__ 
     __syncthreads();
 
     // ---------------- COMPUTE phase ----------------
-    const int n_out = p.TH * p.TW * cb4;
-    for (int item = threadIdx.x; item < n_out; item += kDwThreads) {
-        const int pix = item / cb4;
-        const int ow = pix % p.TW, oh = pix / p.TW;
-        const int goh = th * p.TH + oh, gow = tw * p.TW + ow;
-        if (goh >= p.Ho || gow >= p.Wo || my_c >= p.C) continue;
-        float4 acc = bq;
+    {
+        const int n_pix = p.TH * p.TW;
+        const int dp = kDwThreads >> p.cb4_shift;
+        int pix = pix0;
+        int oh = pix0 / p.TW, ow = pix0 - oh * p.TW;
+        float* yn = y + (size_t)n * p.Ho * p.Wo * p.C + my_c;
+        for (; pix < n_pix; pix += dp) {
+            const int goh = th * p.TH + oh, gow = tw * p.TW + ow;
+            if (goh < p.Ho && gow < p.Wo && c_live) {
+                float4 acc = bq;
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            const float* row = tile + (size_t)((oh * S + kh) * p.IW) * p.CB + my_c4 * 4;
+                for (int kh = 0; kh < 3; ++kh) {
+                    const float* row = tile + (size_t)((oh * S + kh) * p.IW) * p.CB + my_c4 * 4;
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int iw = ow * S + kw;
-                const int slot = (S == 2) ? ((iw & 1) * p.IWh + (iw >> 1)) : iw;
-                const float4 a = *reinterpret_cast<const float4*>(row + slot * p.CB);
-                const float4 w = wt[kh * 3 + kw];
-                acc.x = fmaf(a.x, w.x, acc.x);
-                acc.y = fmaf(a.y, w.y, acc.y);
-                acc.z = fmaf(a.z, w.z, acc.z);
-                acc.w = fmaf(a.w, w.w, acc.w);
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const int iw = ow * S + kw;
+                        const int slot = (S == 2) ? ((iw & 1) * p.IWh + (iw >> 1)) : iw;
+                        const float4 a = *reinterpret_cast<const float4*>(row + slot * p.CB);
+                        const float4 w = wt[kh * 3 + kw];
+                        acc.x = fmaf(a.x, w.x, acc.x);
+                        acc.y = fmaf(a.y, w.y, acc.y);
+                        acc.z = fmaf(a.z, w.z, acc.z);
+                        acc.w = fmaf(a.w, w.w, acc.w);
+                    }
+                }
+                float4 r;  // (out * Ka) * Kw: two float32 roundings, as utils/conv2d_func.py:24
+                r.x = (acc.x * p.ka) * p.kw;
+                r.y = (acc.y * p.ka) * p.kw;
+                r.z = (acc.z * p.ka) * p.kw;
+                r.w = (acc.w * p.ka) * p.kw;
+                *reinterpret_cast<float4*>(yn + ((size_t)goh * p.Wo + gow) * p.C) = r;
             }
+            oh += p.out_step_h;
+            ow += p.out_step_w;
+            if (ow >= p.TW) { ow -= p.TW; ++oh; }
         }
-        float4 r;  // (out * Ka) * Kw: two float32 roundings, as utils/conv2d_func.py:24
-        r.x = (acc.x * p.ka) * p.kw;
-        r.y = (acc.y * p.ka) * p.kw;
-        r.z = (acc.z * p.ka) * p.kw;
-        r.w = (acc.w * p.ka) * p.kw;
-        *reinterpret_cast<float4*>(y + ((((size_t)n * p.Ho + goh) * p.Wo + gow) * p.C + my_c)) = r;
     }
 }
 
@@ -158,9 +175,15 @@ int launch_dw3x3(const slfp_conv2d_desc& d, const ConvPlan& plan, const float* x
     // keep the halo tile within 40 KiB of LDS (>= 3 workgroups per CU)
     while (CB > 4 && (size_t)p.IH * p.IW * CB * sizeof(float) > 40 * 1024) CB /= 2;
     p.CB = CB;
+    p.cb4_shift = 0;
+    while ((4 << p.cb4_shift) < CB) ++p.cb4_shift;
     p.cgroups = p.C / CB;
     p.pad = d.pad_h;
     p.IWh = (p.IW + 1) / 2;
+    const int dp = kDwThreads >> p.cb4_shift;
+    p.in_step_h = dp / p.IW; p.in_step_w = dp % p.IW;
+    p.out_step_h = dp / p.TW; p.out_step_w = dp % p.TW;
+    p.sd = make_scale_div(d.ka);
     p.ka = d.ka; p.kw = d.kw_scale;
     const int64_t nblocks = (int64_t)p.N * p.tiles_h * p.tiles_w * p.cgroups;
     if (nblocks > 0x7FFFFFFF) return fail(SLFP_ERR_UNSUPPORTED, "dw3x3: grid too large");

@@ -2,28 +2,36 @@
 //
 // Replaces Conv2d_Q.forward (utils/conv2d_func.py:20-25 / :41-47) for 1x1 kernels,
 // groups == 1 (the 13 "pw" layers of MobileNetV1, nets_imgnet/mobilenetv1.py:31; the
-// 36 1x1 layers of ResNet-50; Fire squeeze/expand1x1 of SqueezeNet).
+// 36 1x1 layers of ResNet-50; Fire squeeze/expand1x1 of SqueezeNet) and Linear_Q (:60-65).
 //
 // NHWC makes this a plain GEMM  Y^T[N x M] = Wq[N x K] . Xq^T[K x M]  (M = pixels) with
 // K contiguous on both operands.  58 flop/B at float32 would be compute-bound on gfx950
 // (ridge 19.6 flop/B), so the contraction runs on v_mfma_f32_16x16x32_f16 with float32
-// accumulation and the kernel stays HBM-bound (4 B in + 4 B out per element):
-//   * X: every workgroup streams its BM pixel rows once from HBM (16-byte loads, a
-//     pixel's K channels are contiguous), applies x/Ka + the SLFP encode inline, converts
-//     the dequantized value to fp16 (hi [+ lo]) and stages it in a swizzled LDS tile that
-//     all waves of the workgroup share (encode happens once per element);
-//   * W: quantized ONCE per weight update into an MFMA-fragment-ordered fp16 blob
-//     (slfp_conv2d_prepare_weights); each wave streams the fragments of its own output
-//     channels straight from L2 into registers (1 KiB fully coalesced per fragment);
-//   * A operand = W (rows = output channels), B operand = X (columns = pixels), so each
-//     lane ends up holding 4 CONSECUTIVE output channels of one pixel = one 16-byte
-//     NHWC store.
+// accumulation and the kernels stay HBM-bound (4 B in + 4 B out per element).
+//   A operand = W (rows = output channels), B operand = X (columns = pixels): each lane
+//   ends up holding 4 CONSECUTIVE output channels of one pixel = one 16-byte NHWC store.
+//   W is quantized ONCE per weight update into an MFMA-fragment-ordered fp16 blob
+//   (slfp_conv2d_prepare_weights): fragment (n-tile, k-step) is 1 KiB, lane-linear.
+//   Inside a 32-deep k-step lane (col, kq) holds k = {kq*4..kq*4+3, 16+kq*4..16+kq*4+3}
+//   (any k order is legal as long as A and B agree): a lane's two 16-byte X loads then sit
+//   in two 64-byte runs that the wave reads whole.
+// Two kernels, chosen by the size of W:
+//   k_pw_stream  K*N small enough for W to live in LDS (MobileNetV1 pw1-pw5: 71 % of the
+//                pointwise bytes).  Persistent workgroups; a wave's unit of work is 16
+//                pixels: it loads their K channels straight into MFMA B fragments
+//                (x/Ka + SLFP encode inline, no LDS round trip for X, no barriers), sweeps
+//                the W fragments out of LDS, and stores each 16-channel tile as it is done.
+//   k_pw_tiled   larger W: a workgroup owns BM pixels x BN channels; X rows are encoded
+//                once into a swizzled LDS tile shared by its waves (double-buffered over
+//                64-deep K stages), each wave streams the W fragments of its own channels
+//                straight from L2.
 // Operand precision: SFP<3,3> values are exact in fp16 (1 pass, exact products).
 // SLFP<3,4> values are 2^(m/16) multiples; fp16x1 rounds them to 11 bits (~2.5e-4
 // tensor-relative error), fp16x3 splits both operands hi+lo (3 MFMA passes,
-// float32-equivalent).  Both operands are pre-scaled by 2^4 (range [2, 245]) so hi is
-// always a normal fp16 and lo keeps 2^-26 relative precision; the epilogue undoes 2^-8
-// exactly before the reference's (out * Ka) * Kw roundings.
+// float32-equivalent).  Both operands are pre-scaled by 2^4 (range [2, 245]: the scale
+// is folded into the divisor, x/(Ka/16)) so hi is always a normal fp16 and lo keeps 2^-26
+// relative precision; the 2^-8 is folded into the first epilogue scale (power-of-two
+// scaling commutes with rounding), which keeps the reference's (out * Ka) * Kw roundings.
 #include "slfp_device.hpp"
 #include "slfp_host.hpp"
 
@@ -44,10 +52,138 @@ struct PwParams {
     int KS;           // number of 32-deep k-steps in the blob (even)
     int n_tiles;      // 16-row tiles in the blob (n_pad / 16)
     int H, W, Ho, Wo, S;  // strided 1x1: input pixel = (oh*S, ow*S)
-    float ka, s1, s2;     // x/ka; out = ((acc + bias/s1/s2) * s1) * s2
+    ScaleDiv sd;          // divides by Ka/16
+    float s1, s2;         // out = ((acc/256 + bias/s1/s2) * s1) * s2 ; s1x = s1/256
+    float s1x;
     uint32_t m_blocks, n_blocks, nblocks;
 };
 
+// element offset of input pixel row m (strided 1x1 reads pixel (oh*S, ow*S))
+__device__ __forceinline__ size_t x_row_offset(const PwParams& p, int64_t m) {
+    if (p.S == 1) return (size_t)m * p.K;
+    const int64_t hw = (int64_t)p.Ho * p.Wo;
+    const int64_t img = m / hw, r = m - img * hw;
+    const int oh = (int)(r / p.Wo), ow = (int)(r - (int64_t)oh * p.Wo);
+    return (size_t)(((img * p.H) + (int64_t)oh * p.S) * p.W + (int64_t)ow * p.S) * p.K;
+}
+
+template <int FMT, int PASSES>
+__device__ __forceinline__ void encode4(const float4 v, const ScaleDiv sd, const uint32_t* sT, half4& h, half4& l) {
+    const float v0 = quantize_scaled<FMT, 4>(v.x, sd, sT);
+    const float v1 = quantize_scaled<FMT, 4>(v.y, sd, sT);
+    const float v2 = quantize_scaled<FMT, 4>(v.z, sd, sT);
+    const float v3 = quantize_scaled<FMT, 4>(v.w, sd, sT);
+    h[0] = (_Float16)v0; h[1] = (_Float16)v1; h[2] = (_Float16)v2; h[3] = (_Float16)v3;
+    if constexpr (PASSES == 3) {
+        l[0] = (_Float16)(v0 - (float)h[0]); l[1] = (_Float16)(v1 - (float)h[1]);
+        l[2] = (_Float16)(v2 - (float)h[2]); l[3] = (_Float16)(v3 - (float)h[3]);
+    }
+}
+
+__device__ __forceinline__ half8 join(const half4 a, const half4 b) {
+    return half8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+
+// out = ((acc * 2^-8 + bq) * s1) * s2 with the 2^-8 folded: ((acc + 256*bq) * (s1/256)) * s2
+__device__ __forceinline__ float4 epilogue(const floatx4 acc, const float4 bq256, const float s1x, const float s2) {
+    float4 r;
+    r.x = ((acc[0] + bq256.x) * s1x) * s2;
+    r.y = ((acc[1] + bq256.y) * s1x) * s2;
+    r.z = ((acc[2] + bq256.z) * s1x) * s2;
+    r.w = ((acc[3] + bq256.w) * s1x) * s2;
+    return r;
+}
+
+__device__ __forceinline__ float4 bias_q256(const PwParams& p, int n) {
+    if (!p.bias) return make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+    return make_float4(256.f * ((bb.x / p.s1) / p.s2), 256.f * ((bb.y / p.s1) / p.s2),
+                       256.f * ((bb.z / p.s1) / p.s2), 256.f * ((bb.w / p.s1) / p.s2));
+}
+
+// ======================================================================================
+// k_pw_stream: W resident in LDS, X straight into MFMA fragments, 16-pixel work units.
+// ======================================================================================
+constexpr int kStreamThreads = 512;
+
+// KS = number of 32-deep k-steps actually swept (ceil(K/32)); the blob's stride is p.KS.
+template <int FMT, int PASSES, int KS>
+__global__ __launch_bounds__(kStreamThreads) void k_pw_stream(const PwParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* sT = reinterpret_cast<uint32_t*>(smem);
+    _Float16* wl_hi = reinterpret_cast<_Float16*>(smem + 64);
+    const int wfrags = p.n_tiles * p.KS;  // 1 KiB each
+    _Float16* wl_lo = wl_hi + (size_t)wfrags * 512;
+    lut_fill<FMT>(sT);
+    // W blob -> LDS (same fragment order), 16 bytes per thread per step
+    for (int i = threadIdx.x; i < wfrags * 64; i += kStreamThreads) {
+        reinterpret_cast<half8*>(wl_hi)[i] = reinterpret_cast<const half8*>(p.whi)[i];
+        if constexpr (PASSES == 3) reinterpret_cast<half8*>(wl_lo)[i] = reinterpret_cast<const half8*>(p.wlo)[i];
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int col = lane & 15, kq = lane >> 4;
+    const int64_t n_groups = (p.M + 15) >> 4;
+    const int64_t waves_total = (int64_t)gridDim.x * (kStreamThreads / 64);
+    const int64_t wave_id = (int64_t)blockIdx.x * (kStreamThreads / 64) + (threadIdx.x >> 6);
+
+    for (int64_t g = wave_id; g < n_groups; g += waves_total) {
+        const int64_t m = g * 16 + col;
+        const bool live = m < p.M;
+        const float* xr = p.x + (live ? x_row_offset(p, m) : 0) + kq * 4;
+        // ---- X: 2 x 16-byte loads per k-step, CH k-steps (up to 8 loads per lane) in flight
+        // before their encodes
+        constexpr int CH = KS;  // (chunking the loads made hipcc allocate MORE registers, not fewer)
+        half8 xh[KS], xl[KS];
+#pragma unroll
+        for (int c0 = 0; c0 < KS; c0 += CH) {
+            float4 raw[CH][2];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const int k = (c0 + c) * 32 + hf * 16 + kq * 4;
+                    raw[c][hf] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (live && k < p.K) raw[c][hf] = *reinterpret_cast<const float4*>(xr + (c0 + c) * 32 + hf * 16);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                half4 h0, h1, l0, l1;
+                encode4<FMT, PASSES>(raw[c][0], p.sd, sT, h0, l0);
+                encode4<FMT, PASSES>(raw[c][1], p.sd, sT, h1, l1);
+                xh[c0 + c] = join(h0, h1);
+                if constexpr (PASSES == 3) xl[c0 + c] = join(l0, l1);
+            }
+            // keep the chunks sequential: without this hipcc hoists every load of every chunk
+            // to the top and runs out of registers at K = 256
+            if constexpr (KS > CH) asm volatile("" ::: "memory");
+        }
+        // ---- sweep the output-channel tiles
+        float* yr = p.y + (size_t)m * p.N + kq * 4;
+        for (int j = 0; j < p.n_tiles; ++j) {
+            floatx4 acc = floatx4{0.f, 0.f, 0.f, 0.f};
+            const _Float16* wj = wl_hi + ((size_t)j * p.KS) * 512 + lane * 8;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const half8 wh = *reinterpret_cast<const half8*>(wj + ks * 512);
+                if constexpr (PASSES == 3) {
+                    const half8 wl = *reinterpret_cast<const half8*>(wj + (size_t)wfrags * 512 + ks * 512);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[ks], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[ks], acc, 0, 0, 0);
+                }
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[ks], acc, 0, 0, 0);
+            }
+            const int n = j * 16 + kq * 4;
+            if (live && n < p.N) *reinterpret_cast<float4*>(yr + j * 16) = epilogue(acc, bias_q256(p, n), p.s1x, p.s2);
+        }
+    }
+}
+
+// ======================================================================================
+// k_pw_tiled: X via a swizzled LDS tile (encoded once), W fragments straight from L2.
+// ======================================================================================
 __device__ __forceinline__ uint32_t lds_x_off(int row, int chunk16) {
     // 128-byte rows (64 fp16); XOR swizzle so that the 16 rows a fragment read touches hit
     // 16 distinct 16-byte slots (conflict-free ds_read_b128; cdna guide T2)
@@ -55,7 +191,7 @@ __device__ __forceinline__ uint32_t lds_x_off(int row, int chunk16) {
 }
 
 template <int FMT, int PASSES, int WM, int WN, int MT, int NT>
-__global__ __launch_bounds__(64 * WM * WN) void k_pw(const PwParams p) {
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 1) void k_pw_tiled(const PwParams p) {
     constexpr int T = 64 * WM * WN;
     constexpr int BM = WM * MT * 16;
     constexpr int BN = WN * NT * 16;
@@ -66,7 +202,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_pw(const PwParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* sT = reinterpret_cast<uint32_t*>(smem);
     unsigned char* xs = smem + 64;  // [2 buffers][hi, lo][BM rows][128 B]
-    lut_fill(sT);
+    lut_fill<FMT>(sT);
 
     const uint32_t b = xcd_remap(blockIdx.x, p.nblocks);
     const uint32_t nb = b % p.n_blocks, mb = b / p.n_blocks;
@@ -75,25 +211,16 @@ __global__ __launch_bounds__(64 * WM * WN) void k_pw(const PwParams p) {
     const int wm = wave / WN, wn = wave % WN;
     const int col = lane & 15, kq = lane >> 4;
 
-    // ---- per-thread staging geometry: float4 #i covers row (tid>>4) + i*(T/16), k = (tid&15)*4
+    // ---- staging geometry: float4 #i of a thread covers row (tid>>4) + i*(T/16), k = (tid&15)*4.
+    // Inside its 32-deep k-step that float4 is element half (kc&7)>>2 of lane-quarter kc&3.
     const int kc = threadIdx.x & 15;
-    uint32_t src_off[NLD];  // element offset of the row start in x, or 0xFFFFFFFF
+    const int st_chunk = (kc >> 3) * 4 + (kc & 3);
+    const uint32_t st_sub = (uint32_t)((kc & 7) >> 2) * 8u;
+    const float* src[NLD];
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-        const int row = (threadIdx.x >> 4) + i * (T / 16);
-        const int64_t m = m0 + row;
-        uint32_t off = 0xFFFFFFFFu;
-        if (m < p.M) {
-            if (p.S == 1) {
-                off = (uint32_t)(m * p.K);
-            } else {
-                const int64_t hw = (int64_t)p.Ho * p.Wo;
-                const int64_t img = m / hw, r = m % hw;
-                const int oh = (int)(r / p.Wo), ow = (int)(r % p.Wo);
-                off = (uint32_t)((((img * p.H) + (int64_t)oh * p.S) * p.W + (int64_t)ow * p.S) * p.K);
-            }
-        }
-        src_off[i] = off;
+        const int64_t m = m0 + (threadIdx.x >> 4) + i * (T / 16);
+        src[i] = m < p.M ? p.x + x_row_offset(p, m) + kc * 4 : nullptr;
     }
 
     float4 st[NLD];
@@ -102,8 +229,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_pw(const PwParams p) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             st[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (src_off[i] != 0xFFFFFFFFu && k < p.K)
-                st[i] = *reinterpret_cast<const float4*>(p.x + (size_t)src_off[i] + k);
+            if (src[i] != nullptr && k < p.K) st[i] = *reinterpret_cast<const float4*>(src[i] + t * 64);
         }
     };
     auto encode_store = [&](int buf) {
@@ -112,20 +238,11 @@ __global__ __launch_bounds__(64 * WM * WN) void k_pw(const PwParams p) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int row = (threadIdx.x >> 4) + i * (T / 16);
-            const float v0 = 16.0f * quantize_scaled<FMT>(st[i].x, p.ka, sT);
-            const float v1 = 16.0f * quantize_scaled<FMT>(st[i].y, p.ka, sT);
-            const float v2 = 16.0f * quantize_scaled<FMT>(st[i].z, p.ka, sT);
-            const float v3 = 16.0f * quantize_scaled<FMT>(st[i].w, p.ka, sT);
-            half4 h;
-            h[0] = (_Float16)v0; h[1] = (_Float16)v1; h[2] = (_Float16)v2; h[3] = (_Float16)v3;
-            const uint32_t off = lds_x_off(row, kc >> 1) + (uint32_t)(kc & 1) * 8u;
+            half4 h, l;
+            encode4<FMT, PASSES>(st[i], p.sd, sT, h, l);
+            const uint32_t off = lds_x_off(row, st_chunk) + st_sub;
             *reinterpret_cast<half4*>(hi + off) = h;
-            if constexpr (PASSES == 3) {
-                half4 l;
-                l[0] = (_Float16)(v0 - (float)h[0]); l[1] = (_Float16)(v1 - (float)h[1]);
-                l[2] = (_Float16)(v2 - (float)h[2]); l[3] = (_Float16)(v3 - (float)h[3]);
-                *reinterpret_cast<half4*>(lo + off) = l;
-            }
+            if constexpr (PASSES == 3) *reinterpret_cast<half4*>(lo + off) = l;
         }
     };
 
@@ -145,6 +262,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_pw(const PwParams p) {
     if (KT > 1) load_stage(1);
     __syncthreads();
 
+    const size_t wplane = (size_t)(p.wlo - p.whi);
     for (int t = 0; t < KT; ++t) {
         const int buf = t & 1;
         half8 wh[NT], wl[NT];
@@ -152,14 +270,10 @@ __global__ __launch_bounds__(64 * WM * WN) void k_pw(const PwParams p) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int nt = ntile0 + j;
-                if (nt < p.n_tiles) {
-                    const size_t o = ((size_t)nt * p.KS + (size_t)(t * 2 + ks)) * 512 + (size_t)lane * 8;
-                    wh[j] = *reinterpret_cast<const half8*>(p.whi + o);
-                    if constexpr (PASSES == 3) wl[j] = *reinterpret_cast<const half8*>(p.wlo + o);
-                } else {
-                    wh[j] = half8{0, 0, 0, 0, 0, 0, 0, 0};
-                    if constexpr (PASSES == 3) wl[j] = half8{0, 0, 0, 0, 0, 0, 0, 0};
-                }
+                const int ntc = nt < p.n_tiles ? nt : p.n_tiles - 1;  // clamp: padded tiles are never stored
+                const size_t o = ((size_t)ntc * p.KS + (size_t)(t * 2 + ks)) * 512 + (size_t)lane * 8;
+                wh[j] = *reinterpret_cast<const half8*>(p.whi + o);
+                if constexpr (PASSES == 3) wl[j] = *reinterpret_cast<const half8*>(p.whi + wplane + o);
             }
         };
         if (wave_live) load_w(0);
@@ -196,33 +310,32 @@ __global__ __launch_bounds__(64 * WM * WN) void k_pw(const PwParams p) {
         __syncthreads();
     }
 
-    // ---- epilogue: undo the 2^8 operand pre-scale (exact), bias, (out*s1)*s2, 16-byte stores
     if (!wave_live) return;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int n = (ntile0 + j) * 16 + kq * 4;
         if (n >= p.N) continue;
-        float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.bias) {
-            const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
-            bq = make_float4((bb.x / p.s1) / p.s2, (bb.y / p.s1) / p.s2, (bb.z / p.s1) / p.s2, (bb.w / p.s1) / p.s2);
-        }
+        const float4 bq = bias_q256(p, n);
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int64_t m = m0 + (wm * MT + i) * 16 + col;
             if (m >= p.M) continue;
-            float4 r;
-            r.x = ((acc[i][j][0] * 0.00390625f + bq.x) * p.s1) * p.s2;
-            r.y = ((acc[i][j][1] * 0.00390625f + bq.y) * p.s1) * p.s2;
-            r.z = ((acc[i][j][2] * 0.00390625f + bq.z) * p.s1) * p.s2;
-            r.w = ((acc[i][j][3] * 0.00390625f + bq.w) * p.s1) * p.s2;
-            *reinterpret_cast<float4*>(p.y + (size_t)m * p.N + n) = r;
+            *reinterpret_cast<float4*>(p.y + (size_t)m * p.N + n) = epilogue(acc[i][j], bq, p.s1x, p.s2);
         }
     }
 }
 
+// ---------------------------------------------------------------------------- launch
+static int set_lds_limit(const void* fn, size_t lds) {
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return check_launch("hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    }
+    return SLFP_OK;
+}
+
 template <int FMT, int PASSES, int WM, int WN, int MT, int NT>
-static int launch_cfg(PwParams& p, hipStream_t stream) {
+static int launch_tiled(PwParams& p, hipStream_t stream) {
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16, T = 64 * WM * WN;
     p.m_blocks = (uint32_t)ceil_div(p.M, BM);
     p.n_blocks = (uint32_t)ceil_div((int64_t)p.N, BN);
@@ -230,16 +343,59 @@ static int launch_cfg(PwParams& p, hipStream_t stream) {
     if (nblocks > 0x7FFFFFFF) return fail(SLFP_ERR_UNSUPPORTED, "pointwise: grid too large");
     p.nblocks = (uint32_t)nblocks;
     const size_t lds = 64 + (size_t)2 * (PASSES == 3 ? 2 : 1) * BM * 128;
-    hipLaunchKernelGGL((k_pw<FMT, PASSES, WM, WN, MT, NT>), dim3(p.nblocks), dim3(T), lds, stream, p);
-    return check_launch("slfp pointwise kernel");
+    auto fn = k_pw_tiled<FMT, PASSES, WM, WN, MT, NT>;
+    int rc = set_lds_limit(reinterpret_cast<const void*>(fn), lds);
+    if (rc != SLFP_OK) return rc;
+    hipLaunchKernelGGL(fn, dim3(p.nblocks), dim3(T), lds, stream, p);
+    return check_launch("slfp pointwise (tiled) kernel");
+}
+
+template <int FMT, int PASSES, int KS>
+static int launch_stream_ks(PwParams& p, hipStream_t stream) {
+    const size_t lds = 64 + (size_t)(PASSES == 3 ? 2 : 1) * p.n_tiles * p.KS * 1024;
+    auto fn = k_pw_stream<FMT, PASSES, KS>;
+    int rc = set_lds_limit(reinterpret_cast<const void*>(fn), lds);
+    if (rc != SLFP_OK) return rc;
+    // persistent grid: as many workgroups per CU as LDS allows (<= 4), 256 CUs
+    int per_cu = (int)((160 * 1024) / lds);
+    per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+    const int64_t groups = (p.M + 15) / 16;
+    int64_t grid = 256 * per_cu;
+    const int64_t need = ceil_div(groups, kStreamThreads / 64);
+    if (grid > need) grid = need;
+    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(kStreamThreads), lds, stream, p);
+    return check_launch("slfp pointwise (stream) kernel");
+}
+
+// W small enough to live in LDS next to nothing else?
+static bool stream_fits(const ConvPlan& plan, int passes) {
+    const size_t w = (size_t)plan.k_pad * plan.n_pad * 2 * (passes == 3 ? 2 : 1);
+    return plan.k_pad <= 256 && w <= 128 * 1024;
 }
 
 template <int FMT, int PASSES>
-static int launch_by_n(PwParams& p, hipStream_t stream) {
-    if (p.N > 256) return launch_cfg<FMT, PASSES, 1, 8, 8, 4>(p, stream);   // 128 px x 512 ch, 8 waves
-    if (p.N > 128) return launch_cfg<FMT, PASSES, 1, 4, 8, 4>(p, stream);   // 128 px x 256 ch
-    if (p.N > 64) return launch_cfg<FMT, PASSES, 2, 2, 4, 4>(p, stream);    // 128 px x 128 ch
-    return launch_cfg<FMT, PASSES, 4, 1, 2, 4>(p, stream);                   // 128 px x  64 ch
+static int launch_pw(PwParams& p, const ConvPlan& plan, hipStream_t stream) {
+    if (stream_fits(plan, PASSES)) {
+        switch ((p.K + 31) / 32) {  // k-steps that hold real channels (the blob is zero-padded to p.KS)
+            case 1: return launch_stream_ks<FMT, PASSES, 1>(p, stream);
+            case 2: return launch_stream_ks<FMT, PASSES, 2>(p, stream);
+            case 3: return launch_stream_ks<FMT, PASSES, 3>(p, stream);
+            case 4: return launch_stream_ks<FMT, PASSES, 4>(p, stream);
+            case 5: case 6: return launch_stream_ks<FMT, PASSES, 6>(p, stream);
+            case 7: case 8: return launch_stream_ks<FMT, PASSES, 8>(p, stream);
+            default: break;
+        }
+    }
+    if constexpr (PASSES == 3) {
+        if (p.N > 128) return launch_tiled<FMT, 3, 1, 4, 4, 4>(p, stream);  // 64 px x 256 ch
+        if (p.N > 64) return launch_tiled<FMT, 3, 2, 2, 2, 4>(p, stream);   // 64 px x 128 ch
+        return launch_tiled<FMT, 3, 4, 1, 1, 4>(p, stream);                  // 64 px x  64 ch
+    } else {
+        if (p.N > 256) return launch_tiled<FMT, 1, 1, 4, 4, 8>(p, stream);  // 64 px x 512 ch, 2 workgroups/CU
+        if (p.N > 128) return launch_tiled<FMT, 1, 1, 4, 4, 4>(p, stream);  // 64 px x 256 ch
+        if (p.N > 64) return launch_tiled<FMT, 1, 2, 2, 2, 4>(p, stream);   // 64 px x 128 ch
+        return launch_tiled<FMT, 1, 4, 1, 1, 4>(p, stream);                  // 64 px x  64 ch
+    }
 }
 
 int launch_pointwise(const slfp_conv2d_desc& d, const ConvPlan& plan, const float* x, const void* wfrag,
@@ -253,12 +409,11 @@ int launch_pointwise(const slfp_conv2d_desc& d, const ConvPlan& plan, const floa
     p.wlo = p.whi + (size_t)plan.n_pad * plan.k_pad;
     p.H = (int)d.h; p.W = (int)d.w; p.Ho = (int)plan.h_out; p.Wo = (int)plan.w_out; p.S = d.stride_h;
     p.M = d.n * plan.h_out * plan.w_out;
-    p.ka = d.ka; p.s1 = plan.s1; p.s2 = plan.s2;
-    if ((uint64_t)d.n * d.h * d.w * d.c_in >= 0xFFFFFFFFull)
-        return fail(SLFP_ERR_UNSUPPORTED, "pointwise: input larger than 2^32 elements");
-    if (plan.fmt_act == kFmtSfp7) return launch_by_n<kFmtSfp7, 1>(p, stream);  // exact in fp16
-    if (plan.passes == 3) return launch_by_n<kFmtAct8, 3>(p, stream);
-    return launch_by_n<kFmtAct8, 1>(p, stream);
+    p.sd = make_scale_div(d.ka, 4);  // x / (Ka/16) == 16 * (x / Ka)
+    p.s1 = plan.s1; p.s2 = plan.s2; p.s1x = plan.s1 * (1.0f / 256.0f);
+    if (plan.fmt_act == kFmtSfp7) return launch_pw<kFmtSfp7, 1>(p, plan, stream);  // exact in fp16
+    if (plan.passes == 3) return launch_pw<kFmtAct8, 3>(p, plan, stream);
+    return launch_pw<kFmtAct8, 1>(p, plan, stream);
 }
 
 }  // namespace slfp

@@ -3,13 +3,17 @@
 // The reference computes its fake-quantizers with ~25 float32 ATen passes per tensor
 // (utils/sfp_quant.py:32-47 weights, :80-96 activations, :14-30/:63-78 SFP<3,3>).  The
 // result is a pure function of the float32 bit pattern, so here it is one short integer
-// routine that every kernel inlines on its load path:
-//   - exponent extract     = the biased-exponent field of the scaled input,
-//   - mantissa lookup      = RNE of the mantissa to 4 (3) bits with the carry walking into
-//                            the exponent, the 17-entry lin->log map folded into two
-//                            compares, and a 16-entry 2^(m/16) table held in LDS,
-//   - the ordered overrides (tiny -> +-1e-10, [1/16,1/8) -> 1/8, clamp) as selects.
-// Bit-exactness against the reference is pinned by tests/golden (exhaustive sweep).
+// routine that every kernel inlines on its load path (~17 VALU instructions + 1 LDS read):
+//   - exponent extract  = the biased-exponent field after RNE of the mantissa to 4 (3) bits
+//                         (the rounding carry walks into the exponent field by itself),
+//   - mantissa lookup   = a 16-entry LDS table indexed by the rounded mantissa; for
+//                         activations the table already holds 2^(L[lin]/16), i.e. the
+//                         reference's linear-round-then-log double rounding (sfp_quant.py:88-89),
+//   - the ordered overrides (tiny -> +-1e-10, [1/16,1/8) -> 1/8, clamp) as max/selects.
+// `x / Ka` (utils/conv2d_func.py:21) is an IEEE float32 division; with Ka a per-layer
+// constant it is computed by the same Newton/FMA correction sequence the hardware
+// division macro uses, minus the v_rcp and the range scaling (see ScaleDiv below).
+// Bit-exactness against the reference is pinned by tests/golden (exhaustive sweeps).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -29,16 +33,22 @@ constexpr uint32_t kBitsClamp8 = 0x4175257Au;  // float32(15.32165) sfp_quant.py
 constexpr uint32_t kBitsClamp7 = 0x41700000u;  // 15.0              sfp_quant.py:29,77
 constexpr uint32_t kBitsQNaN = 0x7FC00000u;
 
-// 2^(k/16) rounded to float32 (identical to what the reference's pow(2, e + k/16) yields).
+// mantissa field of 2^(k/16) rounded to float32 (what the reference's pow(2, e + k/16) yields)
 static __device__ const uint32_t kT16[16] = {
-    0x3F800000u, 0x3F85AAC3u, 0x3F8B95C2u, 0x3F91C3D3u, 0x3F9837F0u, 0x3F9EF532u,
-    0x3FA5FED7u, 0x3FAD583Fu, 0x3FB504F3u, 0x3FBD08A4u, 0x3FC5672Au, 0x3FCE248Cu,
-    0x3FD744FDu, 0x3FE0CCDFu, 0x3FEAC0C7u, 0x3FF5257Du};
+    0x000000u, 0x05AAC3u, 0x0B95C2u, 0x11C3D3u, 0x1837F0u, 0x1EF532u, 0x25FED7u, 0x2D583Fu,
+    0x3504F3u, 0x3D08A4u, 0x45672Au, 0x4E248Cu, 0x5744FDu, 0x60CCDFu, 0x6AC0C7u, 0x75257Du};
 
-// Copy the 2^(m/16) table into LDS (16 dwords, 16 distinct banks: any per-lane index is
-// conflict-free).  Caller must __syncthreads() before the first lookup.
+// LDS image of the lookup table: 16 dwords in 16 distinct banks, so any per-lane index is
+// conflict-free.  Activations index it with the LINEAR 4-bit mantissa `lin`; the entry is
+// the mantissa of 2^(L[lin]/16) with L = [0,1,3,4,...,14,15,15] (log code 2 unreachable,
+// lin 14 and 15 collide -- SURVEY 8a); weights / decode index it with the log code itself.
+template <int FMT>
 __device__ __forceinline__ void lut_fill(uint32_t* sT) {
-    if (threadIdx.x < 16) sT[threadIdx.x] = kT16[threadIdx.x];
+    if (threadIdx.x < 16) {
+        uint32_t l = threadIdx.x;
+        if (FMT == kFmtAct8) l = l + (l >= 2u ? 1u : 0u) - (l >= 15u ? 1u : 0u);
+        sT[threadIdx.x] = kT16[l];
+    }
 }
 
 // Weight quantizer: #thresholds <= mantissa field, thresholds of round(16*log2(m)) as the
@@ -52,51 +62,56 @@ __device__ __forceinline__ uint32_t w8_log_mantissa(uint32_t f) {
     return m;
 }
 
-// (biased_exponent << MBITS) | mantissa_code of the NORMAL path (valid for 1/8 <= |q| <= clamp;
-// other inputs are overridden by the callers' selects).
-template <int FMT>
-__device__ __forceinline__ uint32_t normal_index(uint32_t a) {
-    if constexpr (FMT == kFmtSfp7) {
-        return (a + 0x7FFFFu + ((a >> 20) & 1u)) >> 20;  // RNE to 3 bits, carry -> exponent
-    } else if constexpr (FMT == kFmtAct8) {
-        const uint32_t lin = (a + 0x3FFFFu + ((a >> 19) & 1u)) >> 19;  // RNE to 4 bits (sfp_quant.py:88)
-        const uint32_t l = lin & 15u;
-        // log converter (sfp_quant.py:89): L = [0,1,3,4,...,14,15,15]
-        return lin + (l >= 2u ? 1u : 0u) - (l >= 15u ? 1u : 0u);
-    } else {
-        return ((a >> 23) << 4) + w8_log_mantissa(a & 0x7FFFFFu);  // m == 16 carries
-    }
-}
-
-// float32 bits of Q_FMT(q) -- bit-identical to the reference's qfn.forward output.
-template <int FMT>
-__device__ __forceinline__ uint32_t quant_bits(uint32_t u, const uint32_t* __restrict__ sT) {
+// float32 bits of 2^ESH * Q_FMT(q), given u = bits(2^ESH * q) and ux = bits(x), the value
+// q was computed from (q = x / Ka with Ka > 0, so sign(q) == sign(x)).  The sign and the NaN
+// test come from x: an infinite or overflowing x turns into NaN inside the FMA division
+// chain (inf - inf), and must still land in the clamp class like the reference's inf / Ka.
+// ESH = 0 everywhere except the pointwise MFMA path, which works on 16*q (ESH = 4) so that
+// the fp16 operands are always normal; scaling by a power of two commutes with every step.
+// `sT` must have been filled by lut_fill<FMT> (lut_fill<kFmtW8> for W8).
+template <int FMT, int ESH = 0>
+__device__ __forceinline__ uint32_t quant_bits(uint32_t u, uint32_t ux, const uint32_t* __restrict__ sT) {
+    constexpr uint32_t E = (uint32_t)ESH << 23;
     const uint32_t a = u & 0x7FFFFFFFu;
-    const uint32_t s = u & 0x80000000u;
-    const uint32_t idx = normal_index<FMT>(a);
     uint32_t v;
     if constexpr (FMT == kFmtSfp7) {
-        v = idx << 20;  // (1 + m/8) * 2^E exactly
-        v = a >= kBitsClamp7 ? kBitsClamp7 : v;
+        // RNE of the mantissa to 3 bits; (1 + m/8) * 2^E is then just the rounded pattern
+        v = (a + 0x7FFFFu + ((a >> 20) & 1u)) & 0xFFF00000u;
+        v = a >= kBitsClamp7 + E ? kBitsClamp7 + E : v;
+    } else if constexpr (FMT == kFmtAct8) {
+        const uint32_t t = a + 0x3FFFFu + ((a >> 19) & 1u);  // RNE to 4 bits (sfp_quant.py:88), carry -> exponent
+        v = (t & 0xFF800000u) | sT[(t >> 19) & 15u];         // log converter folded into the table (:89)
+        v = a > kBitsClamp8 + E ? kBitsClamp8 + E : v;
     } else {
-        v = sT[idx & 15u] + (((idx >> 4) - 127u) << 23);
-        v = a > kBitsClamp8 ? kBitsClamp8 : v;
+        const uint32_t idx = ((a >> 23) << 4) + w8_log_mantissa(a & 0x7FFFFFu);  // m == 16 carries
+        v = ((idx >> 4) << 23) | sT[idx & 15u];
+        v = a > kBitsClamp8 + E ? kBitsClamp8 + E : v;
     }
-    v = a < kBitsEighth ? kBitsEighth : v;
-    v = a < kBitsMin ? kBitsTiny : v;
-    v |= s;
-    v = a == 0u ? 0u : v;               // torch.sign(+-0) == 0
-    v = a > 0x7F800000u ? kBitsQNaN : v;  // NaN in -> NaN out
+    v = v < kBitsEighth + E ? kBitsEighth + E : v;  // [1/16, 1/8) -> 1/8 (the formula gives <= 1/8 there)
+    v = a < kBitsMin + E ? (ESH == 0 ? kBitsTiny : 0x30DBE6FFu /* 16e-10 */) : v;
+    v = (v & 0x7FFFFFFFu) | (ux & 0x80000000u);     // v_bfi: sign of the input
+    v = a == 0u ? 0u : v;                           // torch.sign(+-0) == 0 -> +0 (also on underflow, as x/Ka)
+    v = (ux & 0x7FFFFFFFu) > 0x7F800000u ? kBitsQNaN : v;  // NaN in -> NaN out
     return v;
 }
 
-// canonical (or extended) code byte of Q_FMT(q).
+// canonical (or extended) code byte of Q_FMT(q); u = bits(q).  Not on the hot path.
 template <int FMT>
-__device__ __forceinline__ uint32_t quant_code(uint32_t u, bool ext) {
+__device__ __forceinline__ uint32_t quant_code(uint32_t u, uint32_t ux, bool ext) {
     const uint32_t a = u & 0x7FFFFFFFu;
     constexpr int MB = (FMT == kFmtSfp7) ? 3 : 4;
-    const uint32_t sc = (u >> 31) << (MB + 3);
-    uint32_t c = normal_index<FMT>(a) - (123u << MB);
+    const uint32_t sc = (ux >> 31) << (MB + 3);
+    uint32_t idx;
+    if constexpr (FMT == kFmtSfp7) {
+        idx = (a + 0x7FFFFu + ((a >> 20) & 1u)) >> 20;
+    } else if constexpr (FMT == kFmtAct8) {
+        const uint32_t lin = (a + 0x3FFFFu + ((a >> 19) & 1u)) >> 19;
+        const uint32_t l = lin & 15u;
+        idx = lin + (l >= 2u ? 1u : 0u) - (l >= 15u ? 1u : 0u);
+    } else {
+        idx = ((a >> 23) << 4) + w8_log_mantissa(a & 0x7FFFFFu);
+    }
+    uint32_t c = idx - (123u << MB);
     if constexpr (FMT == kFmtSfp7) {
         c = a >= kBitsClamp7 ? 0x3Fu : c;
     } else {
@@ -106,10 +121,11 @@ __device__ __forceinline__ uint32_t quant_code(uint32_t u, bool ext) {
     c = a < kBitsMin ? 0u : c;
     c |= sc;
     c = a == 0u ? (ext ? 1u : 0u) : c;
-    c = a > 0x7F800000u ? 0u : c;
+    c = (ux & 0x7FFFFFFFu) > 0x7F800000u ? 0u : c;
     return c & 0xFFu;
 }
 
+// code byte -> float32 bits; sT filled by lut_fill<kFmtW8> (identity table).
 template <int FMT>
 __device__ __forceinline__ uint32_t decode_bits(uint32_t code, bool ext, const uint32_t* __restrict__ sT) {
     constexpr int MB = (FMT == kFmtSfp7) ? 3 : 4;
@@ -120,7 +136,7 @@ __device__ __forceinline__ uint32_t decode_bits(uint32_t code, bool ext, const u
         v = (mag + (123u << 3)) << 20;
     } else {
         const uint32_t idx = mag + (123u << 4);
-        v = sT[idx & 15u] + (((idx >> 4) - 127u) << 23);
+        v = ((idx >> 4) << 23) | sT[idx & 15u];
         v = (ext && mag == 2u) ? kBitsClamp8 : v;
     }
     v = mag == 0u ? kBitsTiny : v;
@@ -129,12 +145,36 @@ __device__ __forceinline__ uint32_t decode_bits(uint32_t code, bool ext, const u
     return v;
 }
 
-// Q_FMT(x / scale): the scaled fake-quant of one float.  The division is IEEE float32
-// (hipcc lowers `/` to v_div_scale/v_div_fmas/v_div_fixup unless fast-math is on, which
-// this library never enables): `input/self.Ka` of utils/conv2d_func.py:21.
-template <int FMT>
-__device__ __forceinline__ float quantize_scaled(float x, float scale_div, const uint32_t* __restrict__ sT) {
-    return __uint_as_float(quant_bits<FMT>(__float_as_uint(x / scale_div), sT));
+// ---- x / Ka with Ka a per-launch constant -------------------------------------------------
+// RN(x / d) for every float32 x whose quotient is a normal number, from the host-computed,
+// correctly rounded reciprocal r = RN(1/d):
+//     q0 = RN(x*r);  q1 = fma(fma(-d,q0,x), r, q0);  q = fma(fma(-d,q1,x), r, q1)
+// This is the residual-correction chain of the IEEE division expansion without v_rcp_f32
+// and without the v_div_scale/v_div_fixup range handling.  q0 is within 2 ulp, the first
+// correction makes q1 faithful (its exact value q0 + (x - d*q0)*r differs from x/d by
+// (1 - d*r)(q0 - x/d), a second-order term), and by Markstein's theorem one more
+// correction of a faithful quotient with the correctly rounded reciprocal is the correctly
+// rounded quotient.  Quotients outside the normal range only ever land in the quantizer's
+// "tiny" or "clamp" classes, whose boundaries (1/16, 15.32165) are far inside it; 0 and NaN
+// propagate through the FMAs, inf (or an overflowing x*r) becomes NaN and is classified by
+// quant_bits from the ORIGINAL x.  The host (make_scale_div) refuses divisors
+// outside [1e-30, 1e30].  Equivalence with IEEE `/` is also checked exhaustively on the
+// device over all 2^32 inputs (slfp_debug_div_mismatches; tests/test_gpu_parity.py).
+struct ScaleDiv {
+    float d;  // the divisor (Ka, or Ka/16 on the MFMA path)
+    float r;  // RN(1/d)
+};
+
+__device__ __forceinline__ float div_const(float x, const ScaleDiv s) {
+    const float q0 = x * s.r;
+    const float q1 = __builtin_fmaf(__builtin_fmaf(-s.d, q0, x), s.r, q0);
+    return __builtin_fmaf(__builtin_fmaf(-s.d, q1, x), s.r, q1);
+}
+
+// 2^ESH * Q_FMT(x / Ka) as float32, where s divides by Ka / 2^ESH.
+template <int FMT, int ESH = 0>
+__device__ __forceinline__ float quantize_scaled(float x, const ScaleDiv s, const uint32_t* __restrict__ sT) {
+    return __uint_as_float(quant_bits<FMT, ESH>(__float_as_uint(div_const(x, s)), __float_as_uint(x), sT));
 }
 
 }  // namespace slfp

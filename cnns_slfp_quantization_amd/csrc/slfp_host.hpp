@@ -3,7 +3,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <cmath>
+#include <cstring>
 #include "../../include/slfp.h"
+#include "slfp_device.hpp"
 
 namespace slfp {
 
@@ -16,6 +19,18 @@ int check_launch(const char* what);
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Host side of ScaleDiv (slfp_device.hpp): r = RN(1/d) via double (1/d of a float is never
+// within 2^-53 of a float rounding midpoint unless it is exact, so the double rounding is
+// harmless).  scale_div_ok() is the range the FMA chain is valid for.
+inline bool scale_div_ok(float d) { return std::isfinite(d) && d >= 1e-30f && d <= 1e30f; }
+
+inline ScaleDiv make_scale_div(float d, int esh = 0) {
+    ScaleDiv s;
+    s.d = std::ldexp(d, -esh);  // dividing by d/2^esh == multiplying the quotient by 2^esh, exactly
+    s.r = (float)(1.0 / (double)s.d);
+    return s;
+}
 
 // Kernel families (slfp_conv2d_kernel_name reports them).
 enum KernelFamily { kDw3x3 = 0, kPointwise = 1, kDirect = 2 };

@@ -41,9 +41,9 @@ def test_kernel_selection_and_sizes():
     assert name(_desc(stride_h=2, stride_w=2)) == "dw3x3_nhwc"
     assert name(_desc(c_in=58, c_out=58, groups=58)) == "direct_nhwc"          # ShuffleNetV2 odd width
     pw = _desc(kh=1, kw=1, pad_h=0, pad_w=0, groups=1, c_in=128, c_out=256)
+    assert name(pw) == "pw_mfma_f16x1"                                           # default: one fp16 pass
+    pw.mfma_passes = _lib.MFMA_F16X3
     assert name(pw) == "pw_mfma_f16x3"
-    pw.mfma_passes = _lib.MFMA_F16X1
-    assert name(pw) == "pw_mfma_f16x1"
     pw.qbits = 7
     assert name(pw) == "pw_mfma_f16_exact"                                       # SFP<3,3> is exact in fp16
     assert name(_desc(c_in=3, c_out=32, groups=1, stride_h=2, stride_w=2)) == "direct_nhwc"
@@ -61,6 +61,7 @@ def test_kernel_selection_and_sizes():
     (dict(groups=3), _lib.ERR_SHAPE), (dict(qbits=6), _lib.ERR_BAD_ARG), (dict(qbits=32), _lib.ERR_BAD_ARG),
     (dict(ka=0.0), _lib.ERR_BAD_ARG), (dict(h=1, w=1, pad_h=0, pad_w=0), _lib.ERR_SHAPE),
     (dict(x_layout=7), _lib.ERR_BAD_ARG), (dict(stride_h=0), _lib.ERR_SHAPE), (dict(mfma_passes=2), _lib.ERR_BAD_ARG),
+    (dict(ka=1e-35), _lib.ERR_UNSUPPORTED), (dict(kw_scale=float("inf")), _lib.ERR_UNSUPPORTED),
 ])
 def test_bad_descriptors_return_status_not_crash(bad, code):
     L = _lib.load()

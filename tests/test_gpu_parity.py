@@ -191,14 +191,36 @@ def test_conv_golden_cases(lib, dev, conv_golden, layout, passes):
 def test_linear_golden(dev, conv_golden):
     import utils.conv2d_func as cf
     Ka, Kw = [np.float64(v) for v in conv_golden["linear_scales"]]
-    for q in (8, 7):
-        m = cf.linear_Q(q, Kw, Ka)(64, 10).eval().to(dev)
-        with torch.no_grad():
-            m.weight.copy_(torch.from_numpy(conv_golden["linear_w"]))
-            m.bias.copy_(torch.from_numpy(conv_golden["linear_b"]))
-            y = m(torch.from_numpy(conv_golden["linear_x"]).to(dev))
-        emax, el2 = rel_errors(y.cpu().numpy(), conv_golden[f"linear_q{q}_y"])
-        assert emax <= TOL_EXACT and el2 <= TOL_EXACT, (q, emax, el2)
+    try:
+        for passes, q, tol in ((3, 8, TOL_EXACT), (1, 8, TOL_F16X1), (0, 7, TOL_EXACT)):
+            cf.options.mfma_passes = passes
+            m = cf.linear_Q(q, Kw, Ka)(64, 10).eval().to(dev)
+            with torch.no_grad():
+                m.weight.copy_(torch.from_numpy(conv_golden["linear_w"]))
+                m.bias.copy_(torch.from_numpy(conv_golden["linear_b"]))
+                y = m(torch.from_numpy(conv_golden["linear_x"]).to(dev))
+            emax, el2 = rel_errors(y.cpu().numpy(), conv_golden[f"linear_q{q}_y"])
+            assert emax <= tol and el2 <= tol, (q, passes, emax, el2)
+    finally:
+        cf.options.mfma_passes = 0
+
+
+def test_constant_division_is_ieee_exact_for_all_2_32_inputs(lib, dev):
+    """The kernels compute x/Ka with an FMA chain on a host reciprocal (slfp_device.hpp).
+    Sweep every float32 bit pattern on the device: the quotient must equal IEEE `/` wherever it
+    is a normal number, and no quantizer output may differ anywhere."""
+    L = lib.load()
+    scales = [2.6023073196411133 / 15.5, 13.16812801361084 / 15.5, 1.7093303203582764 / 15.5, 0.21044661104679108 / 15.5,
+              1.0, 3.0, 0.1, 1.0 / 3.0, 1e-3, 977.0,
+              float(np.float32(1.9999999)),                       # all-ones significand
+              float(np.uint32(0x3DFFFFFF).view(np.float32)),      # all-ones significand, 2^-4 binade
+              float(np.nextafter(np.float32(1.0), np.float32(2.0)))]
+    out = torch.zeros(2, dtype=torch.int64, device=dev)
+    for s in scales:
+        for sc in (s, s / 16.0):  # the MFMA path divides by Ka/16
+            lib.check(L.slfp_debug_div_mismatches(float(np.float32(sc)), out.data_ptr(), _stream()))
+            bad = out.cpu().numpy()
+            assert bad[0] == 0 and bad[1] == 0, (sc, bad)
 
 
 # ------------------------------------------------------------------ conv: MobileNetV1 layer shapes vs the oracle
@@ -236,6 +258,7 @@ def _check_against_oracle(lib, dev, N, C, H, O, k, s, p, g, qbits, passes, seed,
     ref = so.conv2d(xs, w.cpu().numpy(), None if b is None else b.cpu().numpy(), s, p, 1, g, Ka, Kw, qbits)
     got = y[idx].permute(0, 3, 1, 2).contiguous().cpu().numpy()
     tol = TOL_F16X1 if kern == "pw_mfma_f16x1" else TOL_EXACT
+    assert (kern == "pw_mfma_f16x1") == (k == 1 and g == 1 and qbits == 8 and passes != 3 and C % 4 == 0 and O % 4 == 0)
     emax, el2 = rel_errors(got, ref)
     assert emax <= tol and el2 <= tol, (kern, (N, C, H, O, k, s), emax, el2)
     return kern, emax, el2
@@ -254,7 +277,7 @@ MBV1 = [(3, 224, 32, 3, 2, 1, 1),
         (1024, 7, 1024, 3, 1, 1, 1024), (1024, 7, 1024, 1, 1, 0, 1)]
 
 
-@pytest.mark.parametrize("qbits, passes", [(8, 3), (8, 1), (7, 0)])
+@pytest.mark.parametrize("qbits, passes", [(8, 3), (8, 0), (7, 0)])
 def test_mobilenetv1_layer_shapes_vs_oracle(lib, dev, qbits, passes):
     kerns = set()
     for i, (C, H, O, k, s, p, g) in enumerate(MBV1):
