@@ -116,7 +116,8 @@ int launch_prepare_weights(const slfp_conv2d_desc& d, const ConvPlan& p, const f
     return check_launch("slfp weight prepare kernel");
 }
 
-static const char* family_name(const ConvPlan& p) {
+static const char* family_name(const ConvPlan& p, const slfp_conv2d_desc& d) {
+    if (p.family == kDirect && stem_applicable(d)) return "stem_nhwc";
     switch (p.family) {
         case kDw3x3: return "dw3x3_nhwc";
         case kPointwise: return p.fmt_act == kFmtSfp7 ? "pw_mfma_f16_exact" : (p.passes == 3 ? "pw_mfma_f16x3" : "pw_mfma_f16x1");
@@ -142,7 +143,7 @@ int slfp_conv2d_out_shape(const slfp_conv2d_desc* d, int64_t* h_out, int64_t* w_
 const char* slfp_conv2d_kernel_name(const slfp_conv2d_desc* d) {
     ConvPlan p;
     if (make_plan(d, &p) != SLFP_OK) return "invalid";
-    return family_name(p);
+    return family_name(p, *d);
 }
 
 size_t slfp_conv2d_wprep_bytes(const slfp_conv2d_desc* d) {

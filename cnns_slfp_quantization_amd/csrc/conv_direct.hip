@@ -130,8 +130,178 @@ __global__ __launch_bounds__(kDirThreads) void k_direct(const float* __restrict_
     }
 }
 
+
+// ======================================================================================
+// k_stem: dense convolution with a tiny C_in (the RGB stems: MobileNetV1 3x3 s2,
+// ResNet-50 / SqueezeNet 7x7 s2, VGG 3x3 s1).  HBM-bound on the OUTPUT side (32..96
+// channels written per 3 read), so the store pattern is what matters:
+//   * one workgroup = one image, an 8 x 16 output tile, all C_out (<= 64, power-of-two / 4 lanes);
+//   * input halo rows are contiguous in NHWC (IW*C floats): coalesced dword loads, encoded once;
+//   * weights ([KH][KW][C][O], the direct-family blob) are copied to LDS once per workgroup;
+//   * lane = (pixel column, 4 output channels): for a fixed output row the lanes of a wave
+//     cover consecutive pixels x all channels = one contiguous run (1 KiB per store
+//     instruction for C_out = 32); each thread walks P rows.
+// ======================================================================================
+constexpr int kStemTH = 8, kStemTW = 16;
+
+struct StemParams {
+    int N, H, W, C, O, KH, KW;
+    int s, ph, pw;
+    int Ho, Wo, tiles_h, tiles_w;
+    int IH, IWC;         // input tile rows, floats per tile row (IW * C)
+    int l4_shift;        // log2(O / 4): lanes per pixel
+    int P;               // output rows per thread
+    int step_h, step_j;  // 256 consecutive floats of the input tile = step_h rows + step_j floats
+    ScaleDiv sd;
+    float s1, s2;
+    uint32_t nblocks;
+};
+
+template <int FMT>
+__global__ __launch_bounds__(256) void k_stem(const float* __restrict__ x, const float* __restrict__ wq,
+                                              const float* __restrict__ bias, float* __restrict__ y, const StemParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* sT = reinterpret_cast<uint32_t*>(smem);
+    float* sW = reinterpret_cast<float*>(smem + 64);            // [KH*KW*C][O]
+    const int n_w = p.KH * p.KW * p.C * p.O;
+    float* tile = sW + ((n_w + 3) & ~3);                         // [IH][IWC]
+    lut_fill<FMT>(sT);
+    for (int i = threadIdx.x * 4; i < n_w; i += 256 * 4)        // O % 4 == 0 -> n_w % 4 == 0, 16-byte aligned blob
+        *reinterpret_cast<float4*>(sW + i) = *reinterpret_cast<const float4*>(wq + i);
+
+    uint32_t b = xcd_remap(blockIdx.x, p.nblocks);
+    const int tw = b % p.tiles_w; b /= p.tiles_w;
+    const int th = b % p.tiles_h; b /= p.tiles_h;
+    const int n = b;
+    const int h_in0 = th * kStemTH * p.s - p.ph, w_in0 = tw * kStemTW * p.s - p.pw;
+    __syncthreads();
+
+    // ---- load + encode the input halo tile (rows are contiguous in NHWC)
+    {
+        const int n_in = p.IH * p.IWC;
+        int idx = threadIdx.x;
+        int ih = idx / p.IWC, j = idx - ih * p.IWC;  // once per thread
+        const float* xn = x + (size_t)n * p.H * p.W * p.C;
+        const int j_lo = -w_in0 * p.C, j_hi = (p.W - w_in0) * p.C;  // valid float range of a tile row
+        constexpr int U = 4;
+        while (idx < n_in) {
+            float v[U];
+            int dst[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int gh = h_in0 + ih;
+                dst[u] = idx < n_in ? ih * p.IWC + j : -1;
+                v[u] = 0.f;
+                if (idx < n_in && gh >= 0 && gh < p.H && j >= j_lo && j < j_hi)
+                    v[u] = xn[((size_t)gh * p.W + w_in0) * p.C + j];
+                idx += 256;
+                ih += p.step_h;
+                j += p.step_j;
+                if (j >= p.IWC) { j -= p.IWC; ++ih; }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (dst[u] >= 0) tile[dst[u]] = quantize_scaled<FMT>(v[u], p.sd, sT);
+        }
+    }
+    __syncthreads();
+
+    // ---- compute: lane = (column, 4 channels), P rows per thread
+    const int l4 = 1 << p.l4_shift;
+    const int c4 = threadIdx.x & (l4 - 1);
+    const int grp = threadIdx.x >> p.l4_shift;
+    const int col = grp & (kStemTW - 1);
+    const int row0 = (grp >> 4) * p.P;
+    constexpr int PMAX = 8;
+    float4 acc[PMAX];
+#pragma unroll
+    for (int q = 0; q < PMAX; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int row_stride = p.s * p.IWC;
+    const float* tbase = tile + (row0 * p.s) * p.IWC + col * p.s * p.C;
+    const float* wbase = sW + c4 * 4;
+    for (int kh = 0; kh < p.KH; ++kh) {
+        for (int kwc = 0; kwc < p.KW * p.C; ++kwc) {  // (kw, ci) are adjacent both in the tile row and in the blob
+            const float4 w = *reinterpret_cast<const float4*>(wbase + (size_t)(kh * p.KW * p.C + kwc) * p.O);
+            const float* a = tbase + kh * p.IWC + kwc;
+#pragma unroll
+            for (int q = 0; q < PMAX; ++q) {
+                if (q < p.P) {
+                    const float av = a[q * row_stride];
+                    acc[q].x = fmaf(av, w.x, acc[q].x);
+                    acc[q].y = fmaf(av, w.y, acc[q].y);
+                    acc[q].z = fmaf(av, w.z, acc[q].z);
+                    acc[q].w = fmaf(av, w.w, acc[q].w);
+                }
+            }
+        }
+    }
+    float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) {
+        const float4 bb = *reinterpret_cast<const float4*>(bias + c4 * 4);
+        bq = make_float4((bb.x / p.s1) / p.s2, (bb.y / p.s1) / p.s2, (bb.z / p.s1) / p.s2, (bb.w / p.s1) / p.s2);
+    }
+    const int gow = tw * kStemTW + col;
+    if (gow >= p.Wo) return;
+#pragma unroll
+    for (int q = 0; q < PMAX; ++q) {
+        const int goh = th * kStemTH + row0 + q;
+        if (q < p.P && goh < p.Ho) {
+            float4 r;
+            r.x = ((acc[q].x + bq.x) * p.s1) * p.s2;
+            r.y = ((acc[q].y + bq.y) * p.s1) * p.s2;
+            r.z = ((acc[q].z + bq.z) * p.s1) * p.s2;
+            r.w = ((acc[q].w + bq.w) * p.s1) * p.s2;
+            *reinterpret_cast<float4*>(y + (((size_t)n * p.Ho + goh) * p.Wo + gow) * p.O + c4 * 4) = r;
+        }
+    }
+}
+
+bool stem_applicable(const slfp_conv2d_desc& d) {
+    const int O = (int)d.c_out, C = (int)d.c_in;
+    if (d.groups != 1 || C > 4 || d.dil_h != 1 || d.dil_w != 1 || d.stride_h != d.stride_w || d.stride_h > 4) return false;
+    if (d.kh == 1 && d.kw == 1) return false;
+    if (O != 16 && O != 32 && O != 64) return false;  // O/4 lanes per pixel: power of two, 16 columns x (O/4) <= 256
+    const size_t n_w = (size_t)d.kh * d.kw * C * O;
+    const size_t ih = (size_t)(kStemTH - 1) * d.stride_h + d.kh, iwc = ((size_t)(kStemTW - 1) * d.stride_w + d.kw) * C;
+    return 64 + (((n_w + 3) & ~(size_t)3) + ih * iwc) * sizeof(float) <= 64 * 1024;
+}
+
+// Returns SLFP_OK if it launched, 1 if this geometry is not a stem (caller falls back).
+static int try_launch_stem(const slfp_conv2d_desc& d, const ConvPlan& plan, const float* x, const float* wq_hwio,
+                           const float* bias, float* y, hipStream_t stream) {
+    const int O = (int)d.c_out, C = (int)d.c_in;
+    if (!stem_applicable(d)) return 1;
+    StemParams p;
+    p.N = (int)d.n; p.H = (int)d.h; p.W = (int)d.w; p.C = C; p.O = O; p.KH = (int)d.kh; p.KW = (int)d.kw;
+    p.s = d.stride_h; p.ph = d.pad_h; p.pw = d.pad_w;
+    p.Ho = (int)plan.h_out; p.Wo = (int)plan.w_out;
+    p.tiles_h = (int)ceil_div(p.Ho, kStemTH); p.tiles_w = (int)ceil_div(p.Wo, kStemTW);
+    p.IH = (kStemTH - 1) * p.s + p.KH;
+    p.IWC = ((kStemTW - 1) * p.s + p.KW) * C;
+    p.l4_shift = O == 16 ? 2 : (O == 32 ? 3 : 4);
+    const int groups = 256 >> p.l4_shift;           // pixel groups: 16 columns x (groups/16) row sets
+    p.P = kStemTH / (groups / kStemTW);             // 2, 4 or 8 rows per thread
+    p.step_h = 256 / p.IWC; p.step_j = 256 % p.IWC;
+    p.sd = make_scale_div(d.ka); p.s1 = plan.s1; p.s2 = plan.s2;
+    const size_t n_w = (size_t)p.KH * p.KW * C * O;
+    const size_t lds = 64 + (((n_w + 3) & ~(size_t)3) + (size_t)p.IH * p.IWC) * sizeof(float);
+    if (lds > 64 * 1024) return 1;
+    const int64_t nblocks = (int64_t)p.N * p.tiles_h * p.tiles_w;
+    if (nblocks > 0x7FFFFFFF) return 1;
+    p.nblocks = (uint32_t)nblocks;
+    if (plan.fmt_act == kFmtAct8)
+        hipLaunchKernelGGL((k_stem<kFmtAct8>), dim3(p.nblocks), dim3(256), lds, stream, x, wq_hwio, bias, y, p);
+    else
+        hipLaunchKernelGGL((k_stem<kFmtSfp7>), dim3(p.nblocks), dim3(256), lds, stream, x, wq_hwio, bias, y, p);
+    return check_launch("slfp stem conv kernel");
+}
+
 int launch_direct(const slfp_conv2d_desc& d, const ConvPlan& plan, const float* x, const float* wq_hwio,
                   const float* bias, float* y, hipStream_t stream) {
+    {
+        const int rc = try_launch_stem(d, plan, x, wq_hwio, bias, y, stream);
+        if (rc <= 0) return rc;  // launched (0) or failed (<0); 1 = not a stem geometry
+    }
     DirParams p;
     p.N = (int)d.n; p.H = (int)d.h; p.W = (int)d.w; p.C = (int)d.c_in; p.O = (int)d.c_out;
     p.KH = (int)d.kh; p.KW = (int)d.kw;

@@ -60,6 +60,21 @@ __global__ __launch_bounds__(kDwThreads) void k_dw3x3(const float* __restrict__ 
     const int pix0 = threadIdx.x >> p.cb4_shift;
     const int h_in0 = th * p.TH * S - p.pad, w_in0 = tw * p.TW * S - p.pad;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // this thread's 4 channels x 9 taps: issued first so that their (L2) latency hides under the tile loads
+    float4 wt[9];
+    float4 bq = zero4;
+    if (c_live) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const float4*>(wq + (size_t)t * p.C + my_c);
+        if (bias) {  // bias_q = bias / Ka / Kw (utils/conv2d_func.py:44)
+            const float4 bb = *reinterpret_cast<const float4*>(bias + my_c);
+            bq = make_float4((bb.x / p.ka) / p.kw, (bb.y / p.ka) / p.kw, (bb.z / p.ka) / p.kw, (bb.w / p.ka) / p.kw);
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wt[t] = zero4;
+    }
     __syncthreads();
 
     // ---------------- LOAD + ENCODE phase ----------------
@@ -69,7 +84,7 @@ __global__ __launch_bounds__(kDwThreads) void k_dw3x3(const float* __restrict__ 
         int pix = pix0;
         int ih = pix0 / p.IW, iw = pix0 - ih * p.IW;  // the only division: once per thread
         const float* xn = x + (size_t)n * p.H * p.W * p.C + my_c;
-        constexpr int U = 4;  // loads kept in flight per thread
+        constexpr int U = 8;  // loads kept in flight per thread (a 16x16x32 halo tile = 8 per thread: one batch)
         while (pix < n_pix) {
             float4 v[U];
             int dst[U];
@@ -100,20 +115,6 @@ __global__ __launch_bounds__(kDwThreads) void k_dw3x3(const float* __restrict__ 
         }
     }
 
-    // this thread's 4 channels x 9 taps
-    float4 wt[9];
-    float4 bq = zero4;
-    if (c_live) {
-#pragma unroll
-        for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const float4*>(wq + (size_t)t * p.C + my_c);
-        if (bias) {  // bias_q = bias / Ka / Kw (utils/conv2d_func.py:44)
-            const float4 bb = *reinterpret_cast<const float4*>(bias + my_c);
-            bq = make_float4((bb.x / p.ka) / p.kw, (bb.y / p.ka) / p.kw, (bb.z / p.ka) / p.kw, (bb.w / p.ka) / p.kw);
-        }
-    } else {
-#pragma unroll
-        for (int t = 0; t < 9; ++t) wt[t] = zero4;
-    }
     __syncthreads();
 
     // ---------------- COMPUTE phase ----------------

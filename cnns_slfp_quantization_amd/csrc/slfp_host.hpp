@@ -58,6 +58,7 @@ int launch_pointwise(const slfp_conv2d_desc& d, const ConvPlan& p, const float* 
                      const float* bias, float* y, hipStream_t stream);
 int launch_direct(const slfp_conv2d_desc& d, const ConvPlan& p, const float* x, const float* wq_hwio,
                   const float* bias, float* y, hipStream_t stream);
+bool stem_applicable(const slfp_conv2d_desc& d);  // direct family: the small-C_in stem kernel takes it
 int launch_prepare_weights(const slfp_conv2d_desc& d, const ConvPlan& p, const float* w_oihw, void* wprep,
                            float* weight_q_oihw, hipStream_t stream);
 

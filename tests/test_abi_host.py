@@ -46,7 +46,8 @@ def test_kernel_selection_and_sizes():
     assert name(pw) == "pw_mfma_f16x3"
     pw.qbits = 7
     assert name(pw) == "pw_mfma_f16_exact"                                       # SFP<3,3> is exact in fp16
-    assert name(_desc(c_in=3, c_out=32, groups=1, stride_h=2, stride_w=2)) == "direct_nhwc"
+    assert name(_desc(c_in=3, c_out=32, groups=1, stride_h=2, stride_w=2)) == "stem_nhwc"
+    assert name(_desc(c_in=16, c_out=32, groups=1)) == "direct_nhwc"
     ho, wo = ctypes.c_int64(), ctypes.c_int64()
     assert L.slfp_conv2d_out_shape(ctypes.byref(_desc(h=224, w=224, c_in=3, c_out=32, groups=1, stride_h=2, stride_w=2)),
                                    ctypes.byref(ho), ctypes.byref(wo)) == 0

@@ -182,7 +182,7 @@ def test_conv_golden_cases(lib, dev, conv_golden, layout, passes):
                 wq_ref = so.quantize(w, np.float32(Kw), so.FMT_W8 if q == 8 else so.FMT_SFP7)
                 assert same_bits(m.weight_q.cpu().numpy(), wq_ref), key
                 assert m.output is y
-        assert {"dw3x3_nhwc", "direct_nhwc", "pw_mfma_f16_exact", "passthrough"} <= seen
+        assert {"dw3x3_nhwc", "direct_nhwc", "stem_nhwc", "pw_mfma_f16_exact", "passthrough"} <= seen
         assert ("pw_mfma_f16x3" if passes == 3 else "pw_mfma_f16x1") in seen
     finally:
         cf.options.mfma_passes = 0
@@ -283,7 +283,7 @@ def test_mobilenetv1_layer_shapes_vs_oracle(lib, dev, qbits, passes):
     for i, (C, H, O, k, s, p, g) in enumerate(MBV1):
         kern, emax, el2 = _check_against_oracle(lib, dev, 2, C, H, O, k, s, p, g, qbits, passes, seed=100 + i)
         kerns.add(kern)
-    assert "dw3x3_nhwc" in kerns and "direct_nhwc" in kerns and any(k.startswith("pw_mfma") for k in kerns)
+    assert "dw3x3_nhwc" in kerns and "stem_nhwc" in kerns and any(k.startswith("pw_mfma") for k in kerns)
 
 
 def test_other_net_shapes_vs_oracle(lib, dev):
