@@ -74,6 +74,28 @@ class Layer:
             _lib.check(rc)
 
 
+FAMILY_KERNELS = {"dw3x3_nhwc": ("k_dw3x3",), "stem_nhwc": ("k_stem",), "direct_nhwc": ("k_direct",),
+                  "pw_mfma_f16x1": ("k_pw_stream", "k_pw_tiled"), "pw_mfma_f16x3": ("k_pw_stream", "k_pw_tiled"),
+                  "pw_mfma_f16_exact": ("k_pw_stream", "k_pw_tiled")}
+
+
+def pmc_traffic(family):
+    """HBM bytes per launch of `family` from the newest committed rocprofv3 PMC summary
+    (profiles/*_summary.json: FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, separate --pmc
+    passes of this same bench command).  Returns (bytes_per_launch, tag) or (None, None)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json")))
+    if not files:
+        return None, None
+    rows = json.load(open(files[-1]))
+    tot = n = 0
+    for r in rows:
+        if r["kernel"].split("<")[0] in FAMILY_KERNELS.get(family, ()) and "hbm_read_MB" in r and "hbm_write_MB" in r:
+            tot += (r["hbm_read_MB"] + r["hbm_write_MB"]) * 1e6 * r["launches"]
+            n += r["launches"]
+    return (int(tot / n), os.path.basename(files[-1]).replace("_summary.json", "")) if n else (None, None)
+
+
 def cpu_baseline(specs, sample_batch, iters):
     """The reference's CPU path re-stated with the same ATen op sequence (oracle/torch_port.py,
     proven bit-identical to the reference in the build container), timed on this box's
@@ -195,6 +217,30 @@ def main():
     dom = fam[dominant]
     dom_gbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
 
+    # ---- the float32-equivalent pointwise mode (fp16 hi/lo split, 3 MFMA passes), same buffers
+    exact_value = None
+    if args.passes == 0:
+        for l in layers:
+            l.desc.mfma_passes = _lib.MFMA_F16X3
+        step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dte = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dte], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dte = float(t.item())
+        exact_value = args.batch * world * args.steps / dte
+        for l in layers:
+            l.desc.mfma_passes = args.passes
+
     if rank == 0:
         imgs = args.batch * world * args.steps
         value = imgs / dt
@@ -214,12 +260,15 @@ def main():
             "algorithmic_bytes_per_image": int(bytes_img),
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(dom_gbs, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(dom_gbs / HBM_PEAK_GBS, 4),
-                         "frac_of_measured_copy_ceiling": round(dom_gbs / HBM_COPY_GBS, 4), "traffic": None,
+                         "frac_of_measured_copy_ceiling": round(dom_gbs / HBM_COPY_GBS, 4),
+                         "traffic": pmc_traffic(dominant)[0], "traffic_profile": pmc_traffic(dominant)[1],
                          "launches_per_step": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
                          "algorithmic_bytes_per_launch": int(dom["bytes"] / dom["launches"])},
             "kernels": {k: {"ms_per_step": round(v["ms"], 4), "GB/s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
                             "launches": v["launches"]} for k, v in fam.items()},
         }
+        if exact_value is not None:
+            out["value_pointwise_f16x3_float32_equivalent"] = round(exact_value, 1)
         if args.per_layer:
             for l, ms in zip(layers, layer_ms):
                 s = l.spec

@@ -252,6 +252,30 @@ def make_conv():
     return out
 
 
+def make_net():
+    """BASELINE config 1: the reference's CIFAR MobileNetV1 (nets_cifar/mobilenetv1.py), batch 8,
+    Qbits 8 and 7, deterministic parameters -> golden logits (+ the first block's activations)."""
+    import types
+    sys.modules.setdefault("torchsummary", types.ModuleType("torchsummary"))
+    sys.modules["torchsummary"].summary = lambda *a, **k: None
+    from nets_cifar.mobilenetv1 import MobileNetV1_Q  # the reference net, unmodified
+    sys.path.insert(2, HERE)
+    import netgen
+    out = {}
+    x = netgen.net_input()
+    for q in (8, 7, 32):
+        m = MobileNetV1_Q(ch_in=3, qbit=q).eval()
+        netgen.fill_parameters(m)
+        with torch.no_grad():
+            logits = m(x.clone())
+            h = m.model[0](x.clone())
+        out[f"logits_q{q}"] = logits.numpy()
+        out[f"block0_q{q}"] = h.numpy()
+        print(f"net q={q}: logits range [{float(logits.min()):.3f}, {float(logits.max()):.3f}], "
+              f"finite={bool(torch.isfinite(logits).all())}, top1={logits.argmax(1).tolist()}")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-sweep", action="store_true")
@@ -267,7 +291,8 @@ def main():
         json.dump(report, open(rep_path, "w"))
     np.savez_compressed(os.path.join(HERE, "codec_golden.npz"), **make_codec(report, rng))
     np.savez_compressed(os.path.join(HERE, "conv_golden.npz"), **make_conv())
-    for f in ("codec_golden.npz", "conv_golden.npz", "sweep_report.json"):
+    np.savez_compressed(os.path.join(HERE, "net_golden.npz"), **make_net())
+    for f in ("codec_golden.npz", "conv_golden.npz", "net_golden.npz", "sweep_report.json"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 

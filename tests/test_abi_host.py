@@ -129,3 +129,41 @@ def test_layerout_composite_keeps_reference_quirks():
     assert y[0].item() == pytest.approx(0.296875) and y[1].item() == pytest.approx(1.0)
     assert y[2].item() == 248.0 and y[3].item() == -248.0
     assert torch.isnan(y[4])  # exact zero -> NaN in the reference too (2^(-8) is XOR there)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/nets_cifar"), reason="reference not mounted (GPU box)")
+def test_reference_nets_run_unmodified_on_the_shim():
+    """In the build container: the reference's own net files import `utils.*` from THIS repo (path
+    order) and construct/run unmodified.  CPU has no quantized compute path, so the forward is
+    checked with q_bit=32 (the passthrough) against the reference running on its own utils."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, types, warnings
+warnings.filterwarnings("ignore")
+first, second = sys.argv[1], sys.argv[2]
+sys.path.insert(0, first); sys.path.insert(1, second)
+sys.modules["torchsummary"] = types.ModuleType("torchsummary"); sys.modules["torchsummary"].summary = lambda *a, **k: None
+import torch, numpy as np
+import utils.conv2d_func as cf
+from nets_cifar.mobilenetv1 import MobileNetV1_Q
+from nets_imgnet.squeezenet1_0 import SqueezeNet
+torch.manual_seed(0)
+m = MobileNetV1_Q(ch_in=3, qbit=32).eval()
+x = torch.randn(2, 3, 32, 32)
+with torch.no_grad():
+    y = m(x)
+q8 = MobileNetV1_Q(ch_in=3, qbit=8)       # constructs (27 Conv2d_Q + Linear_Q) with the array-valued defaults
+sq = SqueezeNet(qbit=7)                   # conv2d_Q_bias users
+n = sum(1 for mod in q8.modules() if isinstance(mod, torch.nn.Conv2d))
+print("FILE", cf.__file__); print("N", n); print("SUM", float(y.double().abs().sum()))
+'''
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    outs = []
+    for first, second in ((ROOT, "/root/reference"), ("/root/reference", ROOT)):
+        r = subprocess.run([sys.executable, "-c", code, first, second], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append(dict(l.split(" ", 1) for l in r.stdout.strip().splitlines()))
+    assert outs[0]["FILE"].startswith(ROOT) and outs[1]["FILE"].startswith("/root/reference")
+    assert outs[0]["N"] == outs[1]["N"] == "27"
+    assert abs(float(outs[0]["SUM"]) - float(outs[1]["SUM"])) <= 1e-4 * abs(float(outs[1]["SUM"]))

@@ -369,3 +369,46 @@ def test_transposes_roundtrip(lib, dev):
     z = torch.empty_like(x)
     lib.check(L.slfp_nhwc_to_nchw_f32(y.data_ptr(), z.data_ptr(), 3, 37, 11, 13, _stream()))
     assert torch.equal(z, x)
+
+
+# ------------------------------------------------------------------ whole net (BASELINE config 1)
+@pytest.mark.parametrize("layout", ["nchw", "channels_last"])
+def test_cifar_mobilenetv1_whole_net(dev, layout):
+    """CIFAR MobileNetV1, batch 8 (BASELINE.json configs[0]): the same deterministic parameters were
+    loaded into the REFERENCE net (nets_cifar/mobilenetv1.py) in the build container to produce
+    tests/golden/net_golden.npz; here the same topology is built from this repo's drop-in
+    Conv2d_Q / Linear_Q (identical state-dict keys).  Chained layers amplify single code flips
+    (SURVEY section 7), so the logits get a looser bar than the per-layer tests."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import netgen
+    import utils.conv2d_func as cf
+    from cnns_slfp_quantization_amd import layer_specs
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "net_golden.npz"))
+    rows = layer_specs.nets()["mobilenetv1_cifar32"]["layers"]
+    scales = [(r["Ka"], r["Kw"]) for r in rows]
+    assert len(scales) == 28 and rows[-1]["kind"] == "linear"
+    x = netgen.net_input().to(dev)
+    if layout == "channels_last":
+        x = x.contiguous(memory_format=torch.channels_last)
+    try:
+        # secondary whole-net bars: fp32-equivalent paths 2e-3; the single-pass fp16 pointwise mode
+        # accumulates its per-layer 2-3e-4 through 27 chained requantizations (measured 2.1e-2)
+        for q, passes, tol in ((8, 3, 2e-3), (8, 0, 5e-2), (7, 0, 2e-3), (32, 0, 1e-4)):
+            cf.options.mfma_passes = passes
+            m = netgen.fill_parameters(netgen.build_mobilenetv1_cifar(cf.conv2d_Q, cf.linear_Q, q, scales)).to(dev).eval()
+            if layout == "channels_last":
+                m = m.to(memory_format=torch.channels_last)
+            with torch.no_grad():
+                h = m.model[0](x)
+                logits = m(x)
+            e0 = rel_errors(h.cpu().numpy(), gold[f"block0_q{q}"])
+            assert max(e0) <= TOL_EXACT, (q, e0)  # first block: stem kernel + stock BN/ReLU
+            e = rel_errors(logits.cpu().numpy(), gold[f"logits_q{q}"])
+            assert max(e) <= tol, (q, passes, e)
+            assert (logits.argmax(1).cpu().numpy() == gold[f"logits_q{q}"].argmax(1)).mean() >= 0.75
+            if q != 32:
+                kinds = {mod._last_kernel for mod in m.modules() if hasattr(mod, "_last_kernel")}
+                assert {"stem_nhwc", "dw3x3_nhwc"} <= kinds and any(k.startswith("pw_mfma") for k in kinds)
+    finally:
+        cf.options.mfma_passes = 0
