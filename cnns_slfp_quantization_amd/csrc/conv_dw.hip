@@ -78,28 +78,35 @@ __global__ __launch_bounds__(kDwThreads) void k_dw3x3(const float* __restrict__ 
     __syncthreads();
 
     // ---------------- LOAD + ENCODE phase ----------------
+    // 32-bit element offsets advanced incrementally (64-bit multiplies per item cost more than
+    // the encode itself: profiles/r01c).
     {
         const int n_pix = p.IH * p.IW;
         const int dp = kDwThreads >> p.cb4_shift;  // pixels between two items of a thread
         int pix = pix0;
         int ih = pix0 / p.IW, iw = pix0 - ih * p.IW;  // the only division: once per thread
+        int gh = h_in0 + ih, gw = w_in0 + iw;
         const float* xn = x + (size_t)n * p.H * p.W * p.C + my_c;
+        int goff = (gh * p.W + gw) * p.C;                               // may be negative outside the image
+        int lrow = ih * p.IW * p.CB + my_c4 * 4;                         // LDS offset of the tile row
+        const int g_step = (p.in_step_h * p.W + p.in_step_w) * p.C, g_wrap = (p.W - p.IW) * p.C;
+        const int l_step = p.in_step_h * p.IW * p.CB, l_wrap = p.IW * p.CB;
         constexpr int U = 8;  // loads kept in flight per thread (a 16x16x32 halo tile = 8 per thread: one batch)
         while (pix < n_pix) {
             float4 v[U];
             int dst[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int gh = h_in0 + ih, gw = w_in0 + iw;
-                const bool inb = pix < n_pix && c_live && gh >= 0 && gh < p.H && gw >= 0 && gw < p.W;
+                const bool live = pix < n_pix;
+                const bool inb = live && c_live && (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W;
                 const int slot = (S == 2) ? ((iw & 1) * p.IWh + (iw >> 1)) : iw;
-                dst[u] = pix < n_pix ? (ih * p.IW + slot) * p.CB + my_c4 * 4 : -1;
+                dst[u] = live ? lrow + slot * p.CB : -1;
                 v[u] = zero4;
-                if (inb) v[u] = *reinterpret_cast<const float4*>(xn + ((size_t)gh * p.W + gw) * p.C);
+                if (inb) v[u] = *reinterpret_cast<const float4*>(xn + (uint32_t)goff);
                 pix += dp;
-                ih += p.in_step_h;
-                iw += p.in_step_w;
-                if (iw >= p.IW) { iw -= p.IW; ++ih; }
+                gh += p.in_step_h; gw += p.in_step_w; iw += p.in_step_w;
+                goff += g_step; lrow += l_step;
+                if (iw >= p.IW) { iw -= p.IW; gw -= p.IW; ++gh; goff += g_wrap; lrow += l_wrap; }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -123,19 +130,30 @@ __global__ __launch_bounds__(kDwThreads) void k_dw3x3(const float* __restrict__ 
         const int dp = kDwThreads >> p.cb4_shift;
         int pix = pix0;
         int oh = pix0 / p.TW, ow = pix0 - oh * p.TW;
+        int goh = th * p.TH + oh, gow = tw * p.TW + ow;
         float* yn = y + (size_t)n * p.Ho * p.Wo * p.C + my_c;
+        int yoff = (goh * p.Wo + gow) * p.C;
+        int lbase = ((oh * S) * p.IW + (S == 1 ? ow : 0)) * p.CB + my_c4 * 4;  // tile offset of the window's first tap
+        const int y_step = (p.out_step_h * p.Wo + p.out_step_w) * p.C, y_wrap = (p.Wo - p.TW) * p.C;
+        const int l_step = (p.out_step_h * S * p.IW + (S == 1 ? p.out_step_w : 0)) * p.CB;
+        const int l_wrap = (S * p.IW - (S == 1 ? p.TW : 0)) * p.CB;
+        const int row_pitch = p.IW * p.CB;
         for (; pix < n_pix; pix += dp) {
-            const int goh = th * p.TH + oh, gow = tw * p.TW + ow;
             if (goh < p.Ho && gow < p.Wo && c_live) {
                 float4 acc = bq;
 #pragma unroll
                 for (int kh = 0; kh < 3; ++kh) {
-                    const float* row = tile + (size_t)((oh * S + kh) * p.IW) * p.CB + my_c4 * 4;
+                    const float* row = tile + lbase + kh * row_pitch;
 #pragma unroll
                     for (int kw = 0; kw < 3; ++kw) {
-                        const int iw = ow * S + kw;
-                        const int slot = (S == 2) ? ((iw & 1) * p.IWh + (iw >> 1)) : iw;
-                        const float4 a = *reinterpret_cast<const float4*>(row + slot * p.CB);
+                        int o;
+                        if (S == 1) {
+                            o = kw * p.CB;
+                        } else {
+                            const int iw = ow * 2 + kw;
+                            o = ((iw & 1) * p.IWh + (iw >> 1)) * p.CB;
+                        }
+                        const float4 a = *reinterpret_cast<const float4*>(row + o);
                         const float4 w = wt[kh * 3 + kw];
                         acc.x = fmaf(a.x, w.x, acc.x);
                         acc.y = fmaf(a.y, w.y, acc.y);
@@ -148,11 +166,12 @@ __global__ __launch_bounds__(kDwThreads) void k_dw3x3(const float* __restrict__ 
                 r.y = (acc.y * p.ka) * p.kw;
                 r.z = (acc.z * p.ka) * p.kw;
                 r.w = (acc.w * p.ka) * p.kw;
-                *reinterpret_cast<float4*>(yn + ((size_t)goh * p.Wo + gow) * p.C) = r;
+                *reinterpret_cast<float4*>(yn + (uint32_t)yoff) = r;
             }
-            oh += p.out_step_h;
-            ow += p.out_step_w;
-            if (ow >= p.TW) { ow -= p.TW; ++oh; }
+            oh += p.out_step_h; goh += p.out_step_h;
+            ow += p.out_step_w; gow += p.out_step_w;
+            yoff += y_step; lbase += l_step;
+            if (ow >= p.TW) { ow -= p.TW; gow -= p.TW; ++oh; ++goh; yoff += y_wrap; lbase += l_wrap; }
         }
     }
 }
@@ -186,6 +205,8 @@ int launch_dw3x3(const slfp_conv2d_desc& d, const ConvPlan& plan, const float* x
     p.out_step_h = dp / p.TW; p.out_step_w = dp % p.TW;
     p.sd = make_scale_div(d.ka);
     p.ka = d.ka; p.kw = d.kw_scale;
+    if ((int64_t)p.H * p.W * p.C >= (1ll << 29) || (int64_t)p.Ho * p.Wo * p.C >= (1ll << 29))
+        return fail(SLFP_ERR_UNSUPPORTED, "dw3x3: one image exceeds 2^29 elements");
     const int64_t nblocks = (int64_t)p.N * p.tiles_h * p.tiles_w * p.cgroups;
     if (nblocks > 0x7FFFFFFF) return fail(SLFP_ERR_UNSUPPORTED, "dw3x3: grid too large");
     p.nblocks = (uint32_t)nblocks;

@@ -62,6 +62,22 @@ __device__ __forceinline__ uint32_t w8_log_mantissa(uint32_t f) {
     return m;
 }
 
+// d = (a & mask) | c in one VALU instruction (hipcc emits v_and + v_or for the C expression).
+__device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t mask, uint32_t c) {
+    uint32_t d;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(mask), "v"(c));
+    return d;
+}
+
+// bits [off, off+width) of x in one VALU instruction (hipcc lowers __builtin_amdgcn_ubfe with
+// constant operands back to shift + and).
+template <int OFF, int WIDTH>
+__device__ __forceinline__ uint32_t bfe(uint32_t x) {
+    uint32_t d;
+    asm("v_bfe_u32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "n"(OFF), "n"(WIDTH));
+    return d;
+}
+
 // float32 bits of 2^ESH * Q_FMT(q), given u = bits(2^ESH * q) and ux = bits(x), the value
 // q was computed from (q = x / Ka with Ka > 0, so sign(q) == sign(x)).  The sign and the NaN
 // test come from x: an infinite or overflowing x turns into NaN inside the FMA division
@@ -69,30 +85,39 @@ __device__ __forceinline__ uint32_t w8_log_mantissa(uint32_t f) {
 // ESH = 0 everywhere except the pointwise MFMA path, which works on 16*q (ESH = 4) so that
 // the fp16 operands are always normal; scaling by a power of two commutes with every step.
 // `sT` must have been filled by lut_fill<FMT> (lut_fill<kFmtW8> for W8).
+// Instruction budget (ACT8): and, bfe, add3, bfe, lshl (LUT address), ds_read, and_or, max,
+// 4 x (cmp + cndmask) [clamp, tiny, zero, NaN], bfi = 16 VALU + 1 LDS; the range tests are
+// float compares on |q| (the abs modifier is free).
 template <int FMT, int ESH = 0>
 __device__ __forceinline__ uint32_t quant_bits(uint32_t u, uint32_t ux, const uint32_t* __restrict__ sT) {
     constexpr uint32_t E = (uint32_t)ESH << 23;
     const uint32_t a = u & 0x7FFFFFFFu;
+    const float aq = fabsf(__uint_as_float(u));
     uint32_t v;
+    bool clamp;
     if constexpr (FMT == kFmtSfp7) {
         // RNE of the mantissa to 3 bits; (1 + m/8) * 2^E is then just the rounded pattern
-        v = (a + 0x7FFFFu + ((a >> 20) & 1u)) & 0xFFF00000u;
-        v = a >= kBitsClamp7 + E ? kBitsClamp7 + E : v;
+        v = (a + 0x7FFFFu + bfe<20, 1>(u)) & 0xFFF00000u;
+        clamp = !(aq < __uint_as_float(kBitsClamp7 + E));  // >= 15 (true for NaN as well)
+        v = clamp ? kBitsClamp7 + E : v;
     } else if constexpr (FMT == kFmtAct8) {
-        const uint32_t t = a + 0x3FFFFu + ((a >> 19) & 1u);  // RNE to 4 bits (sfp_quant.py:88), carry -> exponent
-        v = (t & 0xFF800000u) | sT[(t >> 19) & 15u];         // log converter folded into the table (:89)
-        v = a > kBitsClamp8 + E ? kBitsClamp8 + E : v;
+        const uint32_t t = a + 0x3FFFFu + bfe<19, 1>(u);  // RNE to 4 bits (sfp_quant.py:88), carry -> exponent
+        v = and_or(t, 0xFF800000u, sT[bfe<19, 4>(t)]);    // log converter folded into the table (:89)
+        clamp = !(aq <= __uint_as_float(kBitsClamp8 + E));                  // > 15.32165 (true for NaN as well)
+        v = clamp ? kBitsClamp8 + E : v;
     } else {
         const uint32_t idx = ((a >> 23) << 4) + w8_log_mantissa(a & 0x7FFFFFu);  // m == 16 carries
         v = ((idx >> 4) << 23) | sT[idx & 15u];
-        v = a > kBitsClamp8 + E ? kBitsClamp8 + E : v;
+        clamp = !(aq <= __uint_as_float(kBitsClamp8 + E));
+        v = clamp ? kBitsClamp8 + E : v;
     }
     v = v < kBitsEighth + E ? kBitsEighth + E : v;  // [1/16, 1/8) -> 1/8 (the formula gives <= 1/8 there)
-    v = a < kBitsMin + E ? (ESH == 0 ? kBitsTiny : 0x30DBE6FFu /* 16e-10 */) : v;
-    v = (v & 0x7FFFFFFFu) | (ux & 0x80000000u);     // v_bfi: sign of the input
-    v = a == 0u ? 0u : v;                           // torch.sign(+-0) == 0 -> +0 (also on underflow, as x/Ka)
-    v = (ux & 0x7FFFFFFFu) > 0x7F800000u ? kBitsQNaN : v;  // NaN in -> NaN out
-    return v;
+    v = aq < __uint_as_float(kBitsMin + E) ? (ESH == 0 ? kBitsTiny : 0x30DBE6FFu /* 16e-10 */) : v;
+    float r = copysignf(__uint_as_float(v), __uint_as_float(ux));  // v_bfi: sign of the input
+    r = aq == 0.0f ? 0.0f : r;                                     // torch.sign(+-0) == 0 -> +0 (also on underflow, as x/Ka)
+    const float x = __uint_as_float(ux);
+    r = x != x ? __uint_as_float(kBitsQNaN) : r;                   // NaN in -> NaN out
+    return __float_as_uint(r);
 }
 
 // canonical (or extended) code byte of Q_FMT(q); u = bits(q).  Not on the hot path.
