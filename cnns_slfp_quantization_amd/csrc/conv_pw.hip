@@ -190,7 +190,12 @@ __device__ __forceinline__ uint32_t lds_x_off(int row, int chunk16) {
     return (uint32_t)row * 128u + (uint32_t)((chunk16 ^ (row & 7)) << 4);
 }
 
-template <int FMT, int PASSES, int WM, int WN, int MT, int NT>
+// KFULL: K is a multiple of 64 (no masking of the K tail).  Every global load in the main
+// loop is UNCONDITIONAL (rows beyond M are clamped to the last row and never stored, padded
+// output tiles are clamped and never stored) and the loop body has no branches: with a
+// per-load `if` hipcc cannot count the loads in flight and falls back to s_waitcnt vmcnt(0)
+// in the middle of the MFMA block, draining the HBM loads it has just issued (r01c ISA).
+template <int FMT, int PASSES, int WM, int WN, int MT, int NT, bool KFULL>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 1) void k_pw_tiled(const PwParams p) {
     constexpr int T = 64 * WM * WN;
     constexpr int BM = WM * MT * 16;
@@ -219,17 +224,23 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 1) void k_pw_til
     const float* src[NLD];
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-        const int64_t m = m0 + (threadIdx.x >> 4) + i * (T / 16);
-        src[i] = m < p.M ? p.x + x_row_offset(p, m) + kc * 4 : nullptr;
+        int64_t m = m0 + (threadIdx.x >> 4) + i * (T / 16);
+        m = m < p.M ? m : p.M - 1;  // clamp: rows past the end are computed and dropped
+        src[i] = p.x + x_row_offset(p, m) + kc * 4;
     }
 
     float4 st[NLD];
     auto load_stage = [&](int t) {
-        const int k = t * 64 + kc * 4;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            st[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (src[i] != nullptr && k < p.K) st[i] = *reinterpret_cast<const float4*>(src[i] + t * 64);
+            if constexpr (KFULL) {
+                st[i] = *reinterpret_cast<const float4*>(src[i] + t * 64);
+            } else {
+                const int k = t * 64 + kc * 4;
+                const int kk = k < p.K ? t * 64 : p.K - 4 - kc * 4;  // clamp inside the row
+                st[i] = *reinterpret_cast<const float4*>(src[i] + kk);
+                if (k >= p.K) st[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
     };
     auto encode_store = [&](int buf) {
@@ -254,63 +265,66 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 1) void k_pw_til
 
     const int KT = p.KS >> 1;  // 64-deep stages
     const int ntile0 = (int)nb * (BN / 16) + wn * NT;
-    const bool wave_live = ntile0 < p.n_tiles;  // wave-uniform
+    const size_t wplane = (size_t)(p.wlo - p.whi);
+    const _Float16* wbase[NT];  // fragment (ntile0 + j, k-step 0), lane-linear; padded tiles clamp to the last real one
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int nt = ntile0 + j < p.n_tiles ? ntile0 + j : p.n_tiles - 1;
+        wbase[j] = p.whi + (size_t)nt * p.KS * 512 + (size_t)lane * 8;
+    }
+    half8 wh[NT], wl[NT];
+    auto load_w = [&](int kstep) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            wh[j] = *reinterpret_cast<const half8*>(wbase[j] + (size_t)kstep * 512);
+            if constexpr (PASSES == 3) wl[j] = *reinterpret_cast<const half8*>(wbase[j] + wplane + (size_t)kstep * 512);
+        }
+    };
+    auto mfma_step = [&](int buf, int ks) {
+        const unsigned char* hi = xs + (size_t)buf * (PASSES == 3 ? 2 : 1) * XBYTES;
+        const unsigned char* lo = hi + XBYTES;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int row = (wm * MT + i) * 16 + col;
+            const uint32_t off = lds_x_off(row, ks * 4 + kq);
+            const half8 xh = *reinterpret_cast<const half8*>(hi + off);
+            half8 xl;
+            if constexpr (PASSES == 3) xl = *reinterpret_cast<const half8*>(lo + off);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                if constexpr (PASSES == 3) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[j], xh, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], xl, acc[i][j], 0, 0, 0);
+                }
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], xh, acc[i][j], 0, 0, 0);
+            }
+        }
+    };
 
     __syncthreads();  // LUT visible
     load_stage(0);
     encode_store(0);
-    if (KT > 1) load_stage(1);
+    load_stage(KT > 1 ? 1 : 0);
     __syncthreads();
 
-    const size_t wplane = (size_t)(p.wlo - p.whi);
-    for (int t = 0; t < KT; ++t) {
+    for (int t = 0; t + 1 < KT; ++t) {  // branch-free body
         const int buf = t & 1;
-        half8 wh[NT], wl[NT];
-        auto load_w = [&](int ks) {
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int nt = ntile0 + j;
-                const int ntc = nt < p.n_tiles ? nt : p.n_tiles - 1;  // clamp: padded tiles are never stored
-                const size_t o = ((size_t)ntc * p.KS + (size_t)(t * 2 + ks)) * 512 + (size_t)lane * 8;
-                wh[j] = *reinterpret_cast<const half8*>(p.whi + o);
-                if constexpr (PASSES == 3) wl[j] = *reinterpret_cast<const half8*>(p.whi + wplane + o);
-            }
-        };
-        if (wave_live) load_w(0);
-        // stage t+1: encode the rows fetched one stage ago into the other buffer, then
-        // put stage t+2's loads in flight (they land while this stage's MFMAs run)
-        if (t + 1 < KT) {
-            encode_store(buf ^ 1);
-            if (t + 2 < KT) load_stage(t + 2);
-        }
-        if (wave_live) {
-            const unsigned char* hi = xs + (size_t)buf * (PASSES == 3 ? 2 : 1) * XBYTES;
-            const unsigned char* lo = hi + XBYTES;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                if (ks == 1) load_w(1);
-#pragma unroll
-                for (int i = 0; i < MT; ++i) {
-                    const int row = (wm * MT + i) * 16 + col;
-                    const uint32_t off = lds_x_off(row, ks * 4 + kq);
-                    const half8 xh = *reinterpret_cast<const half8*>(hi + off);
-                    half8 xl;
-                    if constexpr (PASSES == 3) xl = *reinterpret_cast<const half8*>(lo + off);
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) {
-                        if constexpr (PASSES == 3) {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[j], xh, acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], xl, acc[i][j], 0, 0, 0);
-                        }
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], xh, acc[i][j], 0, 0, 0);
-                    }
-                }
-            }
-        }
+        load_w(t * 2);
+        encode_store(buf ^ 1);                       // stage t+1 (fetched one stage ago) -> the other LDS buffer
+        load_stage(t + 2 < KT ? t + 2 : KT - 1);     // stage t+2's HBM loads fly during the MFMAs (last: harmless re-read)
+        mfma_step(buf, 0);
+        load_w(t * 2 + 1);
+        mfma_step(buf, 1);
         __syncthreads();
     }
+    {   // last stage: nothing left to prefetch
+        const int t = KT - 1, buf = t & 1;
+        load_w(t * 2);
+        mfma_step(buf, 0);
+        load_w(t * 2 + 1);
+        mfma_step(buf, 1);
+    }
 
-    if (!wave_live) return;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int n = (ntile0 + j) * 16 + kq * 4;
@@ -334,8 +348,8 @@ static int set_lds_limit(const void* fn, size_t lds) {
     return SLFP_OK;
 }
 
-template <int FMT, int PASSES, int WM, int WN, int MT, int NT>
-static int launch_tiled(PwParams& p, hipStream_t stream) {
+template <int FMT, int PASSES, int WM, int WN, int MT, int NT, bool KFULL>
+static int launch_tiled_k(PwParams& p, hipStream_t stream) {
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16, T = 64 * WM * WN;
     p.m_blocks = (uint32_t)ceil_div(p.M, BM);
     p.n_blocks = (uint32_t)ceil_div((int64_t)p.N, BN);
@@ -343,11 +357,17 @@ static int launch_tiled(PwParams& p, hipStream_t stream) {
     if (nblocks > 0x7FFFFFFF) return fail(SLFP_ERR_UNSUPPORTED, "pointwise: grid too large");
     p.nblocks = (uint32_t)nblocks;
     const size_t lds = 64 + (size_t)2 * (PASSES == 3 ? 2 : 1) * BM * 128;
-    auto fn = k_pw_tiled<FMT, PASSES, WM, WN, MT, NT>;
+    auto fn = k_pw_tiled<FMT, PASSES, WM, WN, MT, NT, KFULL>;
     int rc = set_lds_limit(reinterpret_cast<const void*>(fn), lds);
     if (rc != SLFP_OK) return rc;
     hipLaunchKernelGGL(fn, dim3(p.nblocks), dim3(T), lds, stream, p);
     return check_launch("slfp pointwise (tiled) kernel");
+}
+
+template <int FMT, int PASSES, int WM, int WN, int MT, int NT>
+static int launch_tiled(PwParams& p, hipStream_t stream) {
+    if (p.K % 64 == 0) return launch_tiled_k<FMT, PASSES, WM, WN, MT, NT, true>(p, stream);
+    return launch_tiled_k<FMT, PASSES, WM, WN, MT, NT, false>(p, stream);
 }
 
 template <int FMT, int PASSES, int KS>
