@@ -24,7 +24,13 @@
 //   k_pw_tiled   larger W: a workgroup owns BM pixels x BN channels; X rows are encoded
 //                once into a swizzled LDS tile shared by its waves (double-buffered over
 //                64-deep K stages), each wave streams the W fragments of its own channels
-//                straight from L2.
+//                straight from L2.  Ablation (512->512, 0.081 ms): X loads 0.026, stores
+//                0.021, W 0.014, encode 0.011, MFMA 0: the pieces add up (serial chain per
+//                workgroup), so the tile that maximises co-resident waves won (64 px x 512
+//                ch, 8 waves, 126 VGPRs).  Tried and dropped: deeper X register rings, W
+//                double-buffering (vmcnt retires in order: a W wait drains younger-issued X
+//                loads anyway), a warp-specialised producer/consumer variant (no faster;
+//                MT = 7 tiles spill at the 168-VGPR cap of a 12-wave workgroup).
 // Operand precision: SFP<3,3> values are exact in fp16 (1 pass, exact products).
 // SLFP<3,4> values are 2^(m/16) multiples; fp16x1 rounds them to 11 bits (~2.5e-4
 // tensor-relative error), fp16x3 splits both operands hi+lo (3 MFMA passes,
@@ -32,6 +38,7 @@
 // is folded into the divisor, x/(Ka/16)) so hi is always a normal fp16 and lo keeps 2^-26
 // relative precision; the 2^-8 is folded into the first epilogue scale (power-of-two
 // scaling commutes with rounding), which keeps the reference's (out * Ka) * Kw roundings.
+#include <cstdlib>
 #include "slfp_device.hpp"
 #include "slfp_host.hpp"
 
@@ -196,7 +203,7 @@ __device__ __forceinline__ uint32_t lds_x_off(int row, int chunk16) {
 // per-load `if` hipcc cannot count the loads in flight and falls back to s_waitcnt vmcnt(0)
 // in the middle of the MFMA block, draining the HBM loads it has just issued (r01c ISA).
 template <int FMT, int PASSES, int WM, int WN, int MT, int NT, bool KFULL>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 1) void k_pw_tiled(const PwParams p) {
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 4) void k_pw_tiled(const PwParams p) {
     constexpr int T = 64 * WM * WN;
     constexpr int BM = WM * MT * 16;
     constexpr int BN = WN * NT * 16;
@@ -339,6 +346,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 1) void k_pw_til
     }
 }
 
+
 // ---------------------------------------------------------------------------- launch
 static int set_lds_limit(const void* fn, size_t lds) {
     if (lds > 64 * 1024) {
@@ -411,7 +419,7 @@ static int launch_pw(PwParams& p, const ConvPlan& plan, hipStream_t stream) {
         if (p.N > 64) return launch_tiled<FMT, 3, 2, 2, 2, 4>(p, stream);   // 64 px x 128 ch
         return launch_tiled<FMT, 3, 4, 1, 1, 4>(p, stream);                  // 64 px x  64 ch
     } else {
-        if (p.N > 256) return launch_tiled<FMT, 1, 1, 4, 4, 8>(p, stream);  // 64 px x 512 ch, 2 workgroups/CU
+        if (p.N > 256) return launch_tiled<FMT, 1, 1, 8, 4, 4>(p, stream);  // 64 px x 512 ch, 8 waves, 2 workgroups/CU
         if (p.N > 128) return launch_tiled<FMT, 1, 1, 4, 4, 4>(p, stream);  // 64 px x 256 ch
         if (p.N > 64) return launch_tiled<FMT, 1, 2, 2, 2, 4>(p, stream);   // 64 px x 128 ch
         return launch_tiled<FMT, 1, 4, 1, 1, 4>(p, stream);                  // 64 px x  64 ch
