@@ -412,3 +412,40 @@ def test_cifar_mobilenetv1_whole_net(dev, layout):
                 assert {"stem_nhwc", "dw3x3_nhwc"} <= kinds and any(k.startswith("pw_mfma") for k in kinds)
     finally:
         cf.options.mfma_passes = 0
+
+
+# ------------------------------------------------------------------ every layer geometry of every reference net
+@pytest.mark.parametrize("net", ["vgg16_224", "resnet50_imagenet224", "squeezenet1_0_imagenet224", "shufflenetv2_224",
+                                 "alexnet_imagenet224", "mobilenetv1_cifar32"])
+def test_all_layer_geometries_of_reference_nets(lib, dev, net):
+    """BASELINE.json configs 3-5 (+ AlexNet, CIFAR MobileNetV1) as parity cases: every distinct
+    Conv2d_Q geometry the reference nets instantiate (channels, kernel, stride, padding, groups,
+    bias, per-layer Ka/Kw from data/layer_specs.json), at a reduced spatial size so that the CPU
+    oracle finishes in seconds, in the net's own precision class (SFP<3,3> for SqueezeNet /
+    ShuffleNetV2 as in config 5, SLFP<3,4> otherwise)."""
+    from cnns_slfp_quantization_amd import layer_specs
+    qbits = 7 if net.startswith(("squeezenet", "shufflenet")) else 8
+    seen = set()
+    kernels = set()
+    for li, s in enumerate(layer_specs.conv_layers(net)):
+        key = (s.c_in, s.c_out, s.k, s.stride, s.pad, s.groups, s.bias)
+        if key in seen:
+            continue
+        seen.add(key)
+        hw = max(min(s.h, 15 if s.k[0] <= 3 else 35), s.k[0] + 1)
+        Ka, Kw = s.Ka, s.Kw
+        gen = torch.Generator(device="cpu").manual_seed(7000 + li)
+        w = (torch.randn((s.c_out, s.c_in // s.groups, s.k[0], s.k[1]), generator=gen) * (5.0 * Kw)).to(dev)
+        b = (torch.randn(s.c_out, generator=gen) * 0.5).to(dev) if s.bias else None
+        x = torch.randn((2, hw, hw, s.c_in), generator=gen) * (6.0 * Ka)
+        x = (torch.relu(x) if s.c_in > 3 else x).to(dev)
+        assert s.stride[0] == s.stride[1] and s.pad[0] == s.pad[1]
+        y, kern = _raw_conv(lib, dev, x, w, b, s.stride[0], s.pad[0], s.groups, Ka, Kw, qbits, 0)
+        kernels.add(kern)
+        ref = so.conv2d(x.permute(0, 3, 1, 2).contiguous().cpu().numpy(), w.cpu().numpy(), None if b is None else b.cpu().numpy(),
+                        s.stride[0], s.pad[0], 1, s.groups, Ka, Kw, qbits)
+        got = y.permute(0, 3, 1, 2).contiguous().cpu().numpy()
+        tol = TOL_F16X1 if kern == "pw_mfma_f16x1" else TOL_EXACT
+        emax, el2 = rel_errors(got, ref)
+        assert emax <= tol and el2 <= tol, (net, li, key, kern, emax, el2)
+    assert len(seen) >= 3 and kernels
