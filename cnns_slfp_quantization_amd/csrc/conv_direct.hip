@@ -256,6 +256,101 @@ __global__ __launch_bounds__(256) void k_stem(const float* __restrict__ x, const
     }
 }
 
+
+// Fully specialised stem (compile-time KH, KW, C, stride, O): every LDS address is base +
+// immediate, the 27 (or 147) taps unroll into ds_read + packed FMAs with no index arithmetic
+// (the generic k_stem was VALU-bound: 1225 instructions per wave, profiles/r01c).
+template <int FMT, int KH, int KW, int C, int S, int O>
+__global__ __launch_bounds__(256) void k_stem_fixed(const float* __restrict__ x, const float* __restrict__ wq,
+                                                    const float* __restrict__ bias, float* __restrict__ y,
+                                                    const StemParams p) {
+    constexpr int IH = (kStemTH - 1) * S + KH, IWC = ((kStemTW - 1) * S + KW) * C;
+    constexpr int NW = KH * KW * C * O;
+    constexpr int L4 = O / 4, GROUPS = 256 / L4, P = kStemTH / (GROUPS / kStemTW);
+    static_assert(GROUPS % kStemTW == 0 && P >= 1 && NW % 4 == 0, "unsupported stem shape");
+    __shared__ __attribute__((aligned(16))) float sW[NW];
+    __shared__ __attribute__((aligned(16))) float tile[IH * IWC];
+    __shared__ uint32_t sT[16];
+    lut_fill<FMT>(sT);
+    for (int i = threadIdx.x * 4; i < NW; i += 256 * 4)
+        *reinterpret_cast<float4*>(sW + i) = *reinterpret_cast<const float4*>(wq + i);
+
+    uint32_t b = xcd_remap(blockIdx.x, p.nblocks);
+    const int tw = b % p.tiles_w; b /= p.tiles_w;
+    const int th = b % p.tiles_h; b /= p.tiles_h;
+    const int n = b;
+    const int h_in0 = th * kStemTH * S - p.ph, w_in0 = tw * kStemTW * S - p.pw;
+    __syncthreads();
+
+    {   // load + encode the halo tile: rows are contiguous in NHWC, one dword per lane
+        constexpr int N_IN = IH * IWC, U = (N_IN + 255) / 256;
+        const float* xn = x + (size_t)n * p.H * p.W * C;
+        const int j_lo = -w_in0 * C, j_hi = (p.W - w_in0) * C;
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = threadIdx.x + u * 256;
+            const int ih = idx / IWC, j = idx - ih * IWC;  // compile-time divisor
+            const int gh = h_in0 + ih;
+            v[u] = 0.f;
+            if (idx < N_IN && (unsigned)gh < (unsigned)p.H && j >= j_lo && j < j_hi)
+                v[u] = xn[(gh * p.W + w_in0) * C + j];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = threadIdx.x + u * 256;
+            if (idx < N_IN) tile[idx] = quantize_scaled<FMT>(v[u], p.sd, sT);
+        }
+    }
+    __syncthreads();
+
+    const int c4 = threadIdx.x & (L4 - 1);
+    const int grp = threadIdx.x / L4;
+    const int col = grp & (kStemTW - 1);
+    const int row0 = (grp / kStemTW) * P;
+    float4 acc[P];
+#pragma unroll
+    for (int q = 0; q < P; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* tbase = tile + (row0 * S) * IWC + col * S * C;
+    const float* wbase = sW + c4 * 4;
+#pragma unroll 1  // one kernel row at a time: a full unroll makes hipcc hoist all 135 LDS reads (243 VGPRs)
+    for (int kh = 0; kh < KH; ++kh) {
+        const float* wrow = wbase + kh * KW * C * O;
+        const float* trow = tbase + kh * IWC;
+#pragma unroll
+        for (int kwc = 0; kwc < KW * C; ++kwc) {
+            const float4 w = *reinterpret_cast<const float4*>(wrow + kwc * O);
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                const float av = trow[q * S * IWC + kwc];
+                acc[q].x = fmaf(av, w.x, acc[q].x);
+                acc[q].y = fmaf(av, w.y, acc[q].y);
+                acc[q].z = fmaf(av, w.z, acc[q].z);
+                acc[q].w = fmaf(av, w.w, acc[q].w);
+            }
+        }
+    }
+    float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) {
+        const float4 bb = *reinterpret_cast<const float4*>(bias + c4 * 4);
+        bq = make_float4((bb.x / p.s1) / p.s2, (bb.y / p.s1) / p.s2, (bb.z / p.s1) / p.s2, (bb.w / p.s1) / p.s2);
+    }
+    const int gow = tw * kStemTW + col;
+    if (gow >= p.Wo) return;
+    float* yb = y + (((size_t)n * p.Ho + th * kStemTH + row0) * p.Wo + gow) * O + c4 * 4;
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+        if (th * kStemTH + row0 + q < p.Ho) {
+            float4 r;
+            r.x = ((acc[q].x + bq.x) * p.s1) * p.s2;
+            r.y = ((acc[q].y + bq.y) * p.s1) * p.s2;
+            r.z = ((acc[q].z + bq.z) * p.s1) * p.s2;
+            r.w = ((acc[q].w + bq.w) * p.s1) * p.s2;
+            *reinterpret_cast<float4*>(yb + (uint32_t)(q * p.Wo * O)) = r;
+        }
+    }
+}
+
 bool stem_applicable(const slfp_conv2d_desc& d) {
     const int O = (int)d.c_out, C = (int)d.c_in;
     if (d.groups != 1 || C > 4 || d.dil_h != 1 || d.dil_w != 1 || d.stride_h != d.stride_w || d.stride_h > 4) return false;
@@ -289,6 +384,14 @@ static int try_launch_stem(const slfp_conv2d_desc& d, const ConvPlan& plan, cons
     const int64_t nblocks = (int64_t)p.N * p.tiles_h * p.tiles_w;
     if (nblocks > 0x7FFFFFFF) return 1;
     p.nblocks = (uint32_t)nblocks;
+    if (p.KH == 3 && p.KW == 3 && C == 3 && p.s == 2 && O == 32 && (int64_t)p.H * p.W * C < (1ll << 30)) {
+        // the MobileNetV1 stem (nets_imgnet/mobilenetv1.py:44): fully specialised variant
+        if (plan.fmt_act == kFmtAct8)
+            hipLaunchKernelGGL((k_stem_fixed<kFmtAct8, 3, 3, 3, 2, 32>), dim3(p.nblocks), dim3(256), 0, stream, x, wq_hwio, bias, y, p);
+        else
+            hipLaunchKernelGGL((k_stem_fixed<kFmtSfp7, 3, 3, 3, 2, 32>), dim3(p.nblocks), dim3(256), 0, stream, x, wq_hwio, bias, y, p);
+        return check_launch("slfp stem conv kernel (3x3x3 s2 -> 32)");
+    }
     if (plan.fmt_act == kFmtAct8)
         hipLaunchKernelGGL((k_stem<kFmtAct8>), dim3(p.nblocks), dim3(256), lds, stream, x, wq_hwio, bias, y, p);
     else
