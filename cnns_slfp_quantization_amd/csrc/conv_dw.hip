@@ -29,14 +29,15 @@ struct DwParams {
     int CB, cb4_shift, cgroups;  // channels per block (4 << cb4_shift), #channel groups
     int pad;
     int IH, IW, IWh;             // input tile extent; IWh = (IW+1)/2 (stride-2 de-interleave)
-    int in_step_h, in_step_w;    // (256 >> cb4_shift) pixels = in_step_h rows + in_step_w cols of the input tile
     int out_step_h, out_step_w;  // same for the output tile
     ScaleDiv sd;
     float ka, kw;
     uint32_t nblocks;
 };
 
-template <int FMT, int S>
+// CBT / IWT > 0: channel-group width and input-tile width known at compile time (the MobileNetV1
+// tiles): every LDS offset becomes an immediate and the row-wrap arithmetic folds away.
+template <int FMT, int S, int CBT, int IWT>
 __global__ __launch_bounds__(kDwThreads) void k_dw3x3(const float* __restrict__ x, const float* __restrict__ wq,
                                                       const float* __restrict__ bias, float* __restrict__ y,
                                                       const DwParams p) {
@@ -44,6 +45,12 @@ __global__ __launch_bounds__(kDwThreads) void k_dw3x3(const float* __restrict__ 
     uint32_t* sT = reinterpret_cast<uint32_t*>(smem);      // 16 dwords
     float* tile = reinterpret_cast<float*>(smem + 64);     // [IH][IW][CB]
     lut_fill<FMT>(sT);
+    const int CB = CBT > 0 ? CBT : p.CB;
+    const int IW = IWT > 0 ? IWT : p.IW;
+    const int IWh = (IW + 1) / 2;
+    const int cb4_shift = CBT == 32 ? 3 : (CBT == 64 ? 4 : p.cb4_shift);
+    const int dp = kDwThreads >> cb4_shift;  // pixels between two items of a thread
+    const int in_step_h = dp / IW, in_step_w = dp - in_step_h * IW;
 
     // logical block id -> (channel group, tile_w, tile_h, image); XCD-contiguous so that
     // tiles sharing a halo are served by the same L2.
@@ -53,11 +60,11 @@ __global__ __launch_bounds__(kDwThreads) void k_dw3x3(const float* __restrict__ 
     const int th = b % p.tiles_h; b /= p.tiles_h;
     const int n = b;
 
-    const int cb4 = 1 << p.cb4_shift;
+    const int cb4 = 1 << cb4_shift;
     const int my_c4 = threadIdx.x & (cb4 - 1);  // constant per thread: cb4 divides the block size
-    const int my_c = cg * p.CB + my_c4 * 4;
+    const int my_c = cg * CB + my_c4 * 4;
     const bool c_live = my_c < p.C;
-    const int pix0 = threadIdx.x >> p.cb4_shift;
+    const int pix0 = threadIdx.x >> cb4_shift;
     const int h_in0 = th * p.TH * S - p.pad, w_in0 = tw * p.TW * S - p.pad;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
@@ -81,16 +88,15 @@ __global__ __launch_bounds__(kDwThreads) void k_dw3x3(const float* __restrict__ 
     // 32-bit element offsets advanced incrementally (64-bit multiplies per item cost more than
     // the encode itself: profiles/r01c).
     {
-        const int n_pix = p.IH * p.IW;
-        const int dp = kDwThreads >> p.cb4_shift;  // pixels between two items of a thread
+        const int n_pix = p.IH * IW;
         int pix = pix0;
-        int ih = pix0 / p.IW, iw = pix0 - ih * p.IW;  // the only division: once per thread
+        int ih = pix0 / IW, iw = pix0 - ih * IW;  // the only division: once per thread
         int gh = h_in0 + ih, gw = w_in0 + iw;
         const float* xn = x + (size_t)n * p.H * p.W * p.C + my_c;
         int goff = (gh * p.W + gw) * p.C;                               // may be negative outside the image
-        int lrow = ih * p.IW * p.CB + my_c4 * 4;                         // LDS offset of the tile row
-        const int g_step = (p.in_step_h * p.W + p.in_step_w) * p.C, g_wrap = (p.W - p.IW) * p.C;
-        const int l_step = p.in_step_h * p.IW * p.CB, l_wrap = p.IW * p.CB;
+        int lrow = ih * IW * CB + my_c4 * 4;                         // LDS offset of the tile row
+        const int g_step = (in_step_h * p.W + in_step_w) * p.C, g_wrap = (p.W - IW) * p.C;
+        const int l_step = in_step_h * IW * CB, l_wrap = IW * CB;
         constexpr int U = 8;  // loads kept in flight per thread (a 16x16x32 halo tile = 8 per thread: one batch)
         while (pix < n_pix) {
             float4 v[U];
@@ -99,14 +105,14 @@ __global__ __launch_bounds__(kDwThreads) void k_dw3x3(const float* __restrict__ 
             for (int u = 0; u < U; ++u) {
                 const bool live = pix < n_pix;
                 const bool inb = live && c_live && (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W;
-                const int slot = (S == 2) ? ((iw & 1) * p.IWh + (iw >> 1)) : iw;
-                dst[u] = live ? lrow + slot * p.CB : -1;
+                const int slot = (S == 2) ? ((iw & 1) * IWh + (iw >> 1)) : iw;
+                dst[u] = live ? lrow + slot * CB : -1;
                 v[u] = zero4;
                 if (inb) v[u] = *reinterpret_cast<const float4*>(xn + (uint32_t)goff);
                 pix += dp;
-                gh += p.in_step_h; gw += p.in_step_w; iw += p.in_step_w;
+                gh += in_step_h; gw += in_step_w; iw += in_step_w;
                 goff += g_step; lrow += l_step;
-                if (iw >= p.IW) { iw -= p.IW; gw -= p.IW; ++gh; goff += g_wrap; lrow += l_wrap; }
+                if (in_step_w != 0 && iw >= IW) { iw -= IW; gw -= IW; ++gh; goff += g_wrap; lrow += l_wrap; }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -127,17 +133,16 @@ __global__ __launch_bounds__(kDwThreads) void k_dw3x3(const float* __restrict__ 
     // ---------------- COMPUTE phase ----------------
     {
         const int n_pix = p.TH * p.TW;
-        const int dp = kDwThreads >> p.cb4_shift;
         int pix = pix0;
         int oh = pix0 / p.TW, ow = pix0 - oh * p.TW;
         int goh = th * p.TH + oh, gow = tw * p.TW + ow;
         float* yn = y + (size_t)n * p.Ho * p.Wo * p.C + my_c;
         int yoff = (goh * p.Wo + gow) * p.C;
-        int lbase = ((oh * S) * p.IW + (S == 1 ? ow : 0)) * p.CB + my_c4 * 4;  // tile offset of the window's first tap
+        int lbase = ((oh * S) * IW + (S == 1 ? ow : 0)) * CB + my_c4 * 4;  // tile offset of the window's first tap
         const int y_step = (p.out_step_h * p.Wo + p.out_step_w) * p.C, y_wrap = (p.Wo - p.TW) * p.C;
-        const int l_step = (p.out_step_h * S * p.IW + (S == 1 ? p.out_step_w : 0)) * p.CB;
-        const int l_wrap = (S * p.IW - (S == 1 ? p.TW : 0)) * p.CB;
-        const int row_pitch = p.IW * p.CB;
+        const int l_step = (p.out_step_h * S * IW + (S == 1 ? p.out_step_w : 0)) * CB;
+        const int l_wrap = (S * IW - (S == 1 ? p.TW : 0)) * CB;
+        const int row_pitch = IW * CB;
         for (; pix < n_pix; pix += dp) {
             if (goh < p.Ho && gow < p.Wo && c_live) {
                 float4 acc = bq;
@@ -148,10 +153,10 @@ __global__ __launch_bounds__(kDwThreads) void k_dw3x3(const float* __restrict__ 
                     for (int kw = 0; kw < 3; ++kw) {
                         int o;
                         if (S == 1) {
-                            o = kw * p.CB;
+                            o = kw * CB;
                         } else {
                             const int iw = ow * 2 + kw;
-                            o = ((iw & 1) * p.IWh + (iw >> 1)) * p.CB;
+                            o = ((iw & 1) * IWh + (iw >> 1)) * CB;
                         }
                         const float4 a = *reinterpret_cast<const float4*>(row + o);
                         const float4 w = wt[kh * 3 + kw];
@@ -201,7 +206,6 @@ int launch_dw3x3(const slfp_conv2d_desc& d, const ConvPlan& plan, const float* x
     p.pad = d.pad_h;
     p.IWh = (p.IW + 1) / 2;
     const int dp = kDwThreads >> p.cb4_shift;
-    p.in_step_h = dp / p.IW; p.in_step_w = dp % p.IW;
     p.out_step_h = dp / p.TW; p.out_step_w = dp % p.TW;
     p.sd = make_scale_div(d.ka);
     p.ka = d.ka; p.kw = d.kw_scale;
@@ -213,10 +217,16 @@ int launch_dw3x3(const slfp_conv2d_desc& d, const ConvPlan& plan, const float* x
     const size_t lds = 64 + (size_t)p.IH * p.IW * p.CB * sizeof(float);
     if (lds > 64 * 1024) return fail(SLFP_ERR_UNSUPPORTED, "dw3x3: tile needs %zu B of LDS", lds);
     const bool a8 = plan.fmt_act == kFmtAct8;
-#define SLFP_DW_LAUNCH(FMT, SS) \
-    hipLaunchKernelGGL((k_dw3x3<FMT, SS>), dim3(p.nblocks), dim3(kDwThreads), lds, stream, x, wq9c, bias, y, p)
-    if (S == 1) { if (a8) SLFP_DW_LAUNCH(kFmtAct8, 1); else SLFP_DW_LAUNCH(kFmtSfp7, 1); }
-    else        { if (a8) SLFP_DW_LAUNCH(kFmtAct8, 2); else SLFP_DW_LAUNCH(kFmtSfp7, 2); }
+#define SLFP_DW_LAUNCH(FMT, SS, CBT, IWT) \
+    hipLaunchKernelGGL((k_dw3x3<FMT, SS, CBT, IWT>), dim3(p.nblocks), dim3(kDwThreads), lds, stream, x, wq9c, bias, y, p)
+#define SLFP_DW_BY_FMT(SS, CBT, IWT) \
+    do { if (a8) SLFP_DW_LAUNCH(kFmtAct8, SS, CBT, IWT); else SLFP_DW_LAUNCH(kFmtSfp7, SS, CBT, IWT); } while (0)
+    if (S == 1 && p.CB == 32 && p.IW == 16) SLFP_DW_BY_FMT(1, 32, 16);      // 14x14 tiles (112..14 px layers)
+    else if (S == 1 && p.CB == 64 && p.IW == 9) SLFP_DW_BY_FMT(1, 64, 9);  // 7x7 images, >= 64 channels
+    else if (S == 2 && p.CB == 32 && p.IW == 15) SLFP_DW_BY_FMT(2, 32, 15); // 7x7 output tiles of stride-2 layers
+    else if (S == 1) SLFP_DW_BY_FMT(1, 0, 0);
+    else SLFP_DW_BY_FMT(2, 0, 0);
+#undef SLFP_DW_BY_FMT
 #undef SLFP_DW_LAUNCH
     return check_launch("slfp dw3x3 kernel");
 }

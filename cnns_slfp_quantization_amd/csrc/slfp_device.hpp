@@ -91,21 +91,23 @@ __device__ __forceinline__ uint32_t bfe(uint32_t x) {
 template <int FMT, int ESH = 0>
 __device__ __forceinline__ uint32_t quant_bits(uint32_t u, uint32_t ux, const uint32_t* __restrict__ sT) {
     constexpr uint32_t E = (uint32_t)ESH << 23;
-    const uint32_t a = u & 0x7FFFFFFFu;
-    const float aq = fabsf(__uint_as_float(u));
+    const float aq = fabsf(__uint_as_float(u));  // |q| is a free source modifier on the float compares
     uint32_t v;
     bool clamp;
     if constexpr (FMT == kFmtSfp7) {
         // RNE of the mantissa to 3 bits; (1 + m/8) * 2^E is then just the rounded pattern
-        v = (a + 0x7FFFFu + bfe<20, 1>(u)) & 0xFFF00000u;
+        v = (u + 0x7FFFFu + bfe<20, 1>(u)) & 0x7FF00000u;
         clamp = !(aq < __uint_as_float(kBitsClamp7 + E));  // >= 15 (true for NaN as well)
         v = clamp ? kBitsClamp7 + E : v;
     } else if constexpr (FMT == kFmtAct8) {
-        const uint32_t t = a + 0x3FFFFu + bfe<19, 1>(u);  // RNE to 4 bits (sfp_quant.py:88), carry -> exponent
-        v = and_or(t, 0xFF800000u, sT[bfe<19, 4>(t)]);    // log converter folded into the table (:89)
+        // RNE to 4 bits (sfp_quant.py:88), carry -> exponent; done on the SIGNED pattern (the carry
+        // cannot reach bit 31 for finite q) and the sign is stripped by the and_or mask
+        const uint32_t t = u + 0x3FFFFu + bfe<19, 1>(u);
+        v = and_or(t, 0x7F800000u, sT[bfe<19, 4>(t)]);    // log converter folded into the table (:89)
         clamp = !(aq <= __uint_as_float(kBitsClamp8 + E));                  // > 15.32165 (true for NaN as well)
         v = clamp ? kBitsClamp8 + E : v;
     } else {
+        const uint32_t a = u & 0x7FFFFFFFu;
         const uint32_t idx = ((a >> 23) << 4) + w8_log_mantissa(a & 0x7FFFFFu);  // m == 16 carries
         v = ((idx >> 4) << 23) | sT[idx & 15u];
         clamp = !(aq <= __uint_as_float(kBitsClamp8 + E));
