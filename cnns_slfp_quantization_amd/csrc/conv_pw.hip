@@ -114,7 +114,8 @@ __device__ __forceinline__ float4 bias_q256(const PwParams& p, int n) {
 constexpr int kStreamThreads = 512;
 
 // KS = number of 32-deep k-steps actually swept (ceil(K/32)); the blob's stride is p.KS.
-template <int FMT, int PASSES, int KS>
+// KFULL: K is a multiple of 32.
+template <int FMT, int PASSES, int KS, bool KFULL>
 __global__ __launch_bounds__(kStreamThreads) void k_pw_stream(const PwParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* sT = reinterpret_cast<uint32_t*>(smem);
@@ -138,7 +139,9 @@ __global__ __launch_bounds__(kStreamThreads) void k_pw_stream(const PwParams p) 
     for (int64_t g = wave_id; g < n_groups; g += waves_total) {
         const int64_t m = g * 16 + col;
         const bool live = m < p.M;
-        const float* xr = p.x + (live ? x_row_offset(p, m) : 0) + kq * 4;
+        // unconditional loads (rows past the end are clamped and dropped): hipcc cannot count
+        // conditional loads and falls back to vmcnt(0) waits
+        const float* xr = p.x + x_row_offset(p, live ? m : p.M - 1) + kq * 4;
         // ---- X: 2 x 16-byte loads per k-step, CH k-steps (up to 8 loads per lane) in flight
         // before their encodes
         constexpr int CH = KS;  // (chunking the loads made hipcc allocate MORE registers, not fewer)
@@ -150,9 +153,13 @@ __global__ __launch_bounds__(kStreamThreads) void k_pw_stream(const PwParams p) 
             for (int c = 0; c < CH; ++c) {
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
-                    const int k = (c0 + c) * 32 + hf * 16 + kq * 4;
-                    raw[c][hf] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (live && k < p.K) raw[c][hf] = *reinterpret_cast<const float4*>(xr + (c0 + c) * 32 + hf * 16);
+                    if constexpr (KFULL) {
+                        raw[c][hf] = *reinterpret_cast<const float4*>(xr + (c0 + c) * 32 + hf * 16);
+                    } else {
+                        const int k = (c0 + c) * 32 + hf * 16 + kq * 4;
+                        raw[c][hf] = *reinterpret_cast<const float4*>(xr + (k < p.K ? (c0 + c) * 32 + hf * 16 : p.K - 4 - kq * 4));
+                        if (k >= p.K) raw[c][hf] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
                 }
             }
 #pragma unroll
@@ -381,7 +388,7 @@ static int launch_tiled(PwParams& p, hipStream_t stream) {
 template <int FMT, int PASSES, int KS>
 static int launch_stream_ks(PwParams& p, hipStream_t stream) {
     const size_t lds = 64 + (size_t)(PASSES == 3 ? 2 : 1) * p.n_tiles * p.KS * 1024;
-    auto fn = k_pw_stream<FMT, PASSES, KS>;
+    auto fn = (p.K % 32 == 0) ? k_pw_stream<FMT, PASSES, KS, true> : k_pw_stream<FMT, PASSES, KS, false>;
     int rc = set_lds_limit(reinterpret_cast<const void*>(fn), lds);
     if (rc != SLFP_OK) return rc;
     // persistent grid: as many workgroups per CU as LDS allows (<= 4), 256 CUs
