@@ -20,7 +20,7 @@ SYMBOLS = (
     "slfp_version", "slfp_last_error", "slfp_device_count",
     "slfp_encode_f32", "slfp_decode_f32", "slfp_quantize_f32",
     "slfp_conv2d_out_shape", "slfp_conv2d_kernel_name", "slfp_conv2d_wprep_bytes",
-    "slfp_conv2d_prepare_weights", "slfp_conv2d_workspace_bytes", "slfp_conv2d_fwd",
+    "slfp_conv2d_prepare_weights", "slfp_conv2d_workspace_bytes", "slfp_conv2d_fwd", "slfp_conv2d_fwd_post",
     "slfp_linear_workspace_bytes", "slfp_linear_fwd",
     "slfp_nchw_to_nhwc_f32", "slfp_nhwc_to_nchw_f32", "slfp_debug_div_mismatches",
 )
@@ -73,6 +73,7 @@ def load():
         "slfp_conv2d_prepare_weights": (ci, [dp, vp, vp, vp, vp]),
         "slfp_conv2d_workspace_bytes": (sz, [dp]),
         "slfp_conv2d_fwd": (ci, [dp, vp, vp, vp, vp, vp, vp, vp]),
+        "slfp_conv2d_fwd_post": (ci, [dp, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp]),
         "slfp_linear_workspace_bytes": (sz, [i64, i64, i64]),
         "slfp_linear_fwd": (ci, [vp, vp, vp, vp, i64, i64, i64, cf, cf, ci, ci, vp, vp]),
         "slfp_nchw_to_nhwc_f32": (ci, [vp, vp, i64, i64, i64, i64, vp]),

@@ -136,10 +136,20 @@ def _hip_conv2d(mod, x, weight, bias):
             b = bias.detach()
             b = b if b.is_contiguous() else b.contiguous()
         xq = torch.empty_like(x) if options.eager_stash else None
-        _lib.check(L.slfp_conv2d_fwd(ctypes.byref(d), x.data_ptr(), blob.data_ptr(),
-                                     b.data_ptr() if b is not None else None, y.data_ptr(),
-                                     xq.data_ptr() if xq is not None else None,
-                                     ws.data_ptr() if ws is not None else None, _stream_handle(x)))
+        post = getattr(mod, "_post", None)  # (scale, shift, relu) set by fusion.fuse_bn_relu: eval-BN + ReLU in the epilogue
+        ps = psh = None
+        relu = 0
+        if post is not None:
+            ps, psh, relu = post
+            if ps is not None and ps.device != x.device:
+                ps, psh = ps.to(x.device), psh.to(x.device)
+                mod._post = (ps, psh, relu)
+        _lib.check(L.slfp_conv2d_fwd_post(ctypes.byref(d), x.data_ptr(), blob.data_ptr(),
+                                          b.data_ptr() if b is not None else None,
+                                          ps.data_ptr() if ps is not None else None,
+                                          psh.data_ptr() if psh is not None else None, int(bool(relu)), y.data_ptr(),
+                                          xq.data_ptr() if xq is not None else None,
+                                          ws.data_ptr() if ws is not None else None, _stream_handle(x)))
     mod._last_kernel = L.slfp_conv2d_kernel_name(ctypes.byref(d)).decode()
     mod._last_input = x.detach()
     mod._input_q = xq
@@ -178,6 +188,16 @@ class _SlfpConv2dFn(torch.autograd.Function):
         return gx, gw, gb, None, None
 
 
+def _apply_post_composite(out, post):
+    """The fused epilogue written with stock ATen ops (q_bit == 32 passthrough only)."""
+    if post is None:
+        return out
+    scale, shift, relu = post
+    if scale is not None:
+        out = out * scale.to(out.device).view(1, -1, 1, 1) + shift.to(out.device).view(1, -1, 1, 1)
+    return torch.relu(out) if relu else out
+
+
 def _conv_class(q_bit, Kw, Ka, bias_default, scaled_bias):
     class Conv2d_Q(nn.Conv2d):
         # Kw, Ka are positional arguments 4 and 5 (utils/conv2d_func.py:10-11, :30)
@@ -196,6 +216,8 @@ def _conv_class(q_bit, Kw, Ka, bias_default, scaled_bias):
             self._input_q = None
             self._weight_q32 = None
             self._last_kernel = None
+            self._post = None  # (scale, shift, relu): fused eval-BN + ReLU epilogue (fusion.fuse_bn_relu)
+            self._scaled_bias = scaled_bias
             self.output = None
 
         # -- the reference stores these on every forward (utils/conv2d_func.py:21-22);
@@ -230,12 +252,19 @@ def _conv_class(q_bit, Kw, Ka, bias_default, scaled_bias):
                     b = b / self.Ka / self.Kw
                 self.output = F.conv2d(self._input_q, self._weight_q32, b, self.stride, self.padding,
                                        self.dilation, self.groups) * self.Ka * self.Kw
+                if self.bias is not None and not scaled_bias:
+                    pass  # conv2d_Q hands the raw bias to F.conv2d above (utils/conv2d_func.py:23)
+                self.output = _apply_post_composite(self.output, self._post)
                 return self.output
             if self.q_bit not in (8, 7):
                 raise UnboundLocalError("q_bit must be 32, 8 or 7 (utils/sfp_quant.py:142-147)")
             need_grad = torch.is_grad_enabled() and (input.requires_grad or self.weight.requires_grad or
                                                      (self.bias is not None and self.bias.requires_grad))
-            if need_grad:
+            if self._post is not None and (need_grad and self.training):
+                raise RuntimeError("Conv2d_Q: a fused BN/ReLU epilogue is inference-only; call fusion.unfuse(model) to train")
+            if self._post is not None and self.bias is not None and not scaled_bias:
+                raise NotImplementedError("fused epilogue with conv2d_Q's raw (unscaled) bias is not supported")
+            if need_grad and self._post is None:
                 out = _SlfpConv2dFn.apply(input, self.weight, self.bias, self, scaled_bias)
             else:
                 out = _hip_conv2d(self, input, self.weight, self.bias if scaled_bias else None)

@@ -173,10 +173,21 @@ size_t slfp_conv2d_workspace_bytes(const slfp_conv2d_desc* d) {
 
 int slfp_conv2d_fwd(const slfp_conv2d_desc* d, const float* x, const void* wprep, const float* bias, float* y,
                     float* input_q, void* workspace, void* stream) {
+    return slfp_conv2d_fwd_post(d, x, wprep, bias, nullptr, nullptr, 0, y, input_q, workspace, stream);
+}
+
+int slfp_conv2d_fwd_post(const slfp_conv2d_desc* d, const float* x, const void* wprep, const float* bias,
+                         const float* post_scale, const float* post_shift, int relu, float* y, float* input_q,
+                         void* workspace, void* stream) {
     ConvPlan p;
     int rc = make_plan(d, &p);
     if (rc != SLFP_OK) return rc;
     if (!x || !wprep || !y) return fail(SLFP_ERR_BAD_ARG, "slfp_conv2d_fwd: null pointer");
+    if ((post_scale == nullptr) != (post_shift == nullptr))
+        return fail(SLFP_ERR_BAD_ARG, "slfp_conv2d_fwd_post: post_scale and post_shift must be given together");
+    if (post_scale && (!aligned16(post_scale) || !aligned16(post_shift)))
+        return fail(SLFP_ERR_ALIGNMENT, "slfp_conv2d_fwd_post: post_scale / post_shift must be 16-byte aligned");
+    const PostOp post{post_scale, post_shift, relu ? 1 : 0};
     if (!aligned16(x) || !aligned16(y) || !aligned16(wprep) || (bias && !aligned16(bias)))
         return fail(SLFP_ERR_ALIGNMENT, "slfp_conv2d_fwd: x, y, wprep and bias must be 16-byte aligned");
     hipStream_t st = as_stream(stream);
@@ -199,9 +210,9 @@ int slfp_conv2d_fwd(const slfp_conv2d_desc* d, const float* x, const void* wprep
     }
     if (d->y_layout == SLFP_LAYOUT_NCHW) y_nhwc = reinterpret_cast<float*>(ws);
     switch (p.family) {
-        case kDw3x3: rc = launch_dw3x3(*d, p, x_nhwc, reinterpret_cast<const float*>(wprep), bias, y_nhwc, st); break;
-        case kPointwise: rc = launch_pointwise(*d, p, x_nhwc, wprep, bias, y_nhwc, st); break;
-        default: rc = launch_direct(*d, p, x_nhwc, reinterpret_cast<const float*>(wprep), bias, y_nhwc, st); break;
+        case kDw3x3: rc = launch_dw3x3(*d, p, x_nhwc, reinterpret_cast<const float*>(wprep), bias, post, y_nhwc, st); break;
+        case kPointwise: rc = launch_pointwise(*d, p, x_nhwc, wprep, bias, post, y_nhwc, st); break;
+        default: rc = launch_direct(*d, p, x_nhwc, reinterpret_cast<const float*>(wprep), bias, post, y_nhwc, st); break;
     }
     if (rc != SLFP_OK) return rc;
     if (d->y_layout == SLFP_LAYOUT_NCHW) rc = slfp_nhwc_to_nchw_f32(y_nhwc, y, d->n, d->c_out, p.h_out, p.w_out, stream);
@@ -239,8 +250,9 @@ int slfp_linear_fwd(const float* x, const float* w, const float* bias, float* y,
     if (rc != SLFP_OK) return rc;
     p.s1 = kw_scale;
     p.s2 = ka;
-    if (p.family == kPointwise) return launch_pointwise(d, p, x, workspace, bias, y, st);
-    return launch_direct(d, p, x, reinterpret_cast<const float*>(workspace), bias, y, st);
+    const PostOp none{nullptr, nullptr, 0};
+    if (p.family == kPointwise) return launch_pointwise(d, p, x, workspace, bias, none, y, st);
+    return launch_direct(d, p, x, reinterpret_cast<const float*>(workspace), bias, none, y, st);
 }
 
 }  // extern "C"

@@ -24,6 +24,7 @@ struct DirParams {
     int CC, IH, IW;
     ScaleDiv sd;
     float s1, s2;
+    PostOp post;
     uint32_t nblocks;
 };
 
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(kDirThreads) void k_direct(const float* __restrict_
         if (gow >= p.Wo) continue;
         float r4[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) r4[r] = ((acc[q][r] + bq[r]) * p.s1) * p.s2;
+        for (int r = 0; r < 4; ++r) r4[r] = r < n_o ? post_apply1(((acc[q][r] + bq[r]) * p.s1) * p.s2, p.post, o0 + r) : 0.f;
         float* dst = y + (((size_t)n * p.Ho + goh) * p.Wo + gow) * p.O + o0;
         if (o_vec) {
             *reinterpret_cast<float4*>(dst) = make_float4(r4[0], r4[1], r4[2], r4[3]);
@@ -154,6 +155,7 @@ struct StemParams {
     int step_h, step_j;  // 256 consecutive floats of the input tile = step_h rows + step_j floats
     ScaleDiv sd;
     float s1, s2;
+    PostOp post;
     uint32_t nblocks;
 };
 
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(256) void k_stem(const float* __restrict__ x, const
             r.y = ((acc[q].y + bq.y) * p.s1) * p.s2;
             r.z = ((acc[q].z + bq.z) * p.s1) * p.s2;
             r.w = ((acc[q].w + bq.w) * p.s1) * p.s2;
-            *reinterpret_cast<float4*>(y + (((size_t)n * p.Ho + goh) * p.Wo + gow) * p.O + c4 * 4) = r;
+            *reinterpret_cast<float4*>(y + (((size_t)n * p.Ho + goh) * p.Wo + gow) * p.O + c4 * 4) = post_apply(r, p.post, c4 * 4);
         }
     }
 }
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(256) void k_stem_fixed(const float* __restrict__ x,
             r.y = ((acc[q].y + bq.y) * p.s1) * p.s2;
             r.z = ((acc[q].z + bq.z) * p.s1) * p.s2;
             r.w = ((acc[q].w + bq.w) * p.s1) * p.s2;
-            *reinterpret_cast<float4*>(yb + (uint32_t)(q * p.Wo * O)) = r;
+            *reinterpret_cast<float4*>(yb + (uint32_t)(q * p.Wo * O)) = post_apply(r, p.post, c4 * 4);
         }
     }
 }
@@ -363,10 +365,11 @@ bool stem_applicable(const slfp_conv2d_desc& d) {
 
 // Returns SLFP_OK if it launched, 1 if this geometry is not a stem (caller falls back).
 static int try_launch_stem(const slfp_conv2d_desc& d, const ConvPlan& plan, const float* x, const float* wq_hwio,
-                           const float* bias, float* y, hipStream_t stream) {
+                           const float* bias, const PostOp& post, float* y, hipStream_t stream) {
     const int O = (int)d.c_out, C = (int)d.c_in;
     if (!stem_applicable(d)) return 1;
     StemParams p;
+    p.post = post;
     p.N = (int)d.n; p.H = (int)d.h; p.W = (int)d.w; p.C = C; p.O = O; p.KH = (int)d.kh; p.KW = (int)d.kw;
     p.s = d.stride_h; p.ph = d.pad_h; p.pw = d.pad_w;
     p.Ho = (int)plan.h_out; p.Wo = (int)plan.w_out;
@@ -400,12 +403,13 @@ static int try_launch_stem(const slfp_conv2d_desc& d, const ConvPlan& plan, cons
 }
 
 int launch_direct(const slfp_conv2d_desc& d, const ConvPlan& plan, const float* x, const float* wq_hwio,
-                  const float* bias, float* y, hipStream_t stream) {
+                  const float* bias, const PostOp& post, float* y, hipStream_t stream) {
     {
-        const int rc = try_launch_stem(d, plan, x, wq_hwio, bias, y, stream);
+        const int rc = try_launch_stem(d, plan, x, wq_hwio, bias, post, y, stream);
         if (rc <= 0) return rc;  // launched (0) or failed (<0); 1 = not a stem geometry
     }
     DirParams p;
+    p.post = post;
     p.N = (int)d.n; p.H = (int)d.h; p.W = (int)d.w; p.C = (int)d.c_in; p.O = (int)d.c_out;
     p.KH = (int)d.kh; p.KW = (int)d.kw;
     p.sh = d.stride_h; p.sw = d.stride_w; p.ph = d.pad_h; p.pw = d.pad_w; p.dh = d.dil_h; p.dw = d.dil_w;

@@ -32,6 +32,7 @@ struct DwParams {
     int out_step_h, out_step_w;  // same for the output tile
     ScaleDiv sd;
     float ka, kw;
+    PostOp post;
     uint32_t nblocks;
 };
 
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(kDwThreads) void k_dw3x3(const float* __restrict__ 
                 r.y = (acc.y * p.ka) * p.kw;
                 r.z = (acc.z * p.ka) * p.kw;
                 r.w = (acc.w * p.ka) * p.kw;
-                *reinterpret_cast<float4*>(yn + (uint32_t)yoff) = r;
+                *reinterpret_cast<float4*>(yn + (uint32_t)yoff) = post_apply(r, p.post, my_c);
             }
             oh += p.out_step_h; goh += p.out_step_h;
             ow += p.out_step_w; gow += p.out_step_w;
@@ -182,8 +183,9 @@ __global__ __launch_bounds__(kDwThreads) void k_dw3x3(const float* __restrict__ 
 }
 
 int launch_dw3x3(const slfp_conv2d_desc& d, const ConvPlan& plan, const float* x, const float* wq9c,
-                 const float* bias, float* y, hipStream_t stream) {
+                 const float* bias, const PostOp& post, float* y, hipStream_t stream) {
     DwParams p;
+    p.post = post;
     p.N = (int)d.n; p.H = (int)d.h; p.W = (int)d.w; p.C = (int)d.c_in;
     p.Ho = (int)plan.h_out; p.Wo = (int)plan.w_out;
     const int S = d.stride_h;

@@ -63,6 +63,7 @@ struct PwParams {
     float s1, s2;         // out = ((acc/256 + bias/s1/s2) * s1) * s2 ; s1x = s1/256
     float s1x;
     uint32_t m_blocks, n_blocks, nblocks;
+    PostOp post;
 };
 
 // element offset of input pixel row m (strided 1x1 reads pixel (oh*S, ow*S))
@@ -190,7 +191,8 @@ __global__ __launch_bounds__(kStreamThreads) void k_pw_stream(const PwParams p) 
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[ks], acc, 0, 0, 0);
             }
             const int n = j * 16 + kq * 4;
-            if (live && n < p.N) *reinterpret_cast<float4*>(yr + j * 16) = epilogue(acc, bias_q256(p, n), p.s1x, p.s2);
+            if (live && n < p.N)
+                *reinterpret_cast<float4*>(yr + j * 16) = post_apply(epilogue(acc, bias_q256(p, n), p.s1x, p.s2), p.post, n);
         }
     }
 }
@@ -348,7 +350,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 4) void k_pw_til
         for (int i = 0; i < MT; ++i) {
             const int64_t m = m0 + (wm * MT + i) * 16 + col;
             if (m >= p.M) continue;
-            *reinterpret_cast<float4*>(p.y + (size_t)m * p.N + n) = epilogue(acc[i][j], bq, p.s1x, p.s2);
+            *reinterpret_cast<float4*>(p.y + (size_t)m * p.N + n) = post_apply(epilogue(acc[i][j], bq, p.s1x, p.s2), p.post, n);
         }
     }
 }
@@ -434,8 +436,9 @@ static int launch_pw(PwParams& p, const ConvPlan& plan, hipStream_t stream) {
 }
 
 int launch_pointwise(const slfp_conv2d_desc& d, const ConvPlan& plan, const float* x, const void* wfrag,
-                     const float* bias, float* y, hipStream_t stream) {
+                     const float* bias, const PostOp& post, float* y, hipStream_t stream) {
     PwParams p;
+    p.post = post;
     p.x = x; p.bias = bias; p.y = y;
     p.K = (int)d.c_in; p.N = (int)d.c_out;
     p.KS = (int)(plan.k_pad / 32);

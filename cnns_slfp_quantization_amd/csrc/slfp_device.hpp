@@ -198,6 +198,34 @@ __device__ __forceinline__ float div_const(float x, const ScaleDiv s) {
     return __builtin_fmaf(__builtin_fmaf(-s.d, q1, x), s.r, q1);
 }
 
+// Optional per-output-channel post-op applied AFTER the reference's (out * Ka) * Kw roundings:
+// y = max(r * scale[c] + shift[c], 0).  With scale = gamma / sqrt(var + eps) and
+// shift = beta - mean * scale this is the eval-mode BatchNorm2d + ReLU that follows every
+// Conv2d_Q in the reference nets (nets_imgnet/mobilenetv1.py:24-41), fused into the epilogue
+// (SURVEY 8f rank 1).  scale == nullptr: no affine; relu == 0: no clamp.
+struct PostOp {
+    const float* scale;
+    const float* shift;
+    int relu;
+};
+
+__device__ __forceinline__ float4 post_apply(float4 r, const PostOp po, int c) {
+    if (po.scale) {
+        const float4 sc = *reinterpret_cast<const float4*>(po.scale + c);
+        const float4 sh = *reinterpret_cast<const float4*>(po.shift + c);
+        r.x = __builtin_fmaf(r.x, sc.x, sh.x); r.y = __builtin_fmaf(r.y, sc.y, sh.y);
+        r.z = __builtin_fmaf(r.z, sc.z, sh.z); r.w = __builtin_fmaf(r.w, sc.w, sh.w);
+    }
+    if (po.relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+    return r;
+}
+
+__device__ __forceinline__ float post_apply1(float r, const PostOp po, int c) {
+    if (po.scale) r = __builtin_fmaf(r, po.scale[c], po.shift[c]);
+    if (po.relu) r = fmaxf(r, 0.f);
+    return r;
+}
+
 // 2^ESH * Q_FMT(x / Ka) as float32, where s divides by Ka / 2^ESH.
 template <int FMT, int ESH = 0>
 __device__ __forceinline__ float quantize_scaled(float x, const ScaleDiv s, const uint32_t* __restrict__ sT) {

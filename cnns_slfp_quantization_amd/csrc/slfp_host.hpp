@@ -53,11 +53,11 @@ int make_plan(const slfp_conv2d_desc* d, ConvPlan* plan);
 // ---- launchers implemented next to their kernels (all NHWC, all async on `stream`) ----
 int launch_quantize(const float* x, float* y, size_t n, float scale, int fmt, hipStream_t stream);
 int launch_dw3x3(const slfp_conv2d_desc& d, const ConvPlan& p, const float* x, const float* wq9c,
-                 const float* bias, float* y, hipStream_t stream);
+                 const float* bias, const PostOp& post, float* y, hipStream_t stream);
 int launch_pointwise(const slfp_conv2d_desc& d, const ConvPlan& p, const float* x, const void* wfrag,
-                     const float* bias, float* y, hipStream_t stream);
+                     const float* bias, const PostOp& post, float* y, hipStream_t stream);
 int launch_direct(const slfp_conv2d_desc& d, const ConvPlan& p, const float* x, const float* wq_hwio,
-                  const float* bias, float* y, hipStream_t stream);
+                  const float* bias, const PostOp& post, float* y, hipStream_t stream);
 bool stem_applicable(const slfp_conv2d_desc& d);  // direct family: the small-C_in stem kernel takes it
 int launch_prepare_weights(const slfp_conv2d_desc& d, const ConvPlan& p, const float* w_oihw, void* wprep,
                            float* weight_q_oihw, hipStream_t stream);

@@ -110,6 +110,16 @@ size_t slfp_conv2d_workspace_bytes(const slfp_conv2d_desc* d);
 int slfp_conv2d_fwd(const slfp_conv2d_desc* d, const float* x, const void* wprep, const float* bias,
                     float* y, float* input_q, void* workspace, void* stream);
 
+/* Same, with the eval-mode BatchNorm2d (+ ReLU) that follows every Conv2d_Q in the reference
+ * nets (nets_imgnet/mobilenetv1.py:24-41, resnet50.py:74-88) fused into the epilogue (SURVEY 8f
+ * rank 1):   y = act(conv_q_out * post_scale[c] + post_shift[c]),  act = max(., 0) if relu.
+ * post_scale = gamma / sqrt(running_var + eps), post_shift = beta - running_mean * post_scale,
+ * float32[C_out], 16-byte aligned; both NULL = no affine.  The conv result itself keeps the
+ * reference's (out * Ka) * Kw roundings; the affine is one fused multiply-add on top. */
+int slfp_conv2d_fwd_post(const slfp_conv2d_desc* d, const float* x, const void* wprep, const float* bias,
+                         const float* post_scale, const float* post_shift, int relu, float* y,
+                         float* input_q, void* workspace, void* stream);
+
 /* ---- linear: replaces Linear_Q.forward (utils/conv2d_func.py:60-65) -------------------
  * out = linear(QA(x/Ka), QW(w/Kw), bias/Kw/Ka) * Kw * Ka   (note the Kw-first order).
  * x: [batch, in_f] row-major, w: [out_f, in_f] row-major, bias: [out_f] or NULL.  The weights

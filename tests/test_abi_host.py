@@ -167,3 +167,30 @@ print("FILE", cf.__file__); print("N", n); print("SUM", float(y.double().abs().s
     assert outs[0]["FILE"].startswith(ROOT) and outs[1]["FILE"].startswith("/root/reference")
     assert outs[0]["N"] == outs[1]["N"] == "27"
     assert abs(float(outs[0]["SUM"]) - float(outs[1]["SUM"])) <= 1e-4 * abs(float(outs[1]["SUM"]))
+
+
+def test_fuse_bn_relu_host_logic():
+    """fusion.fuse_bn_relu on the q_bit=32 passthrough (CPU): BN/ReLU folded into the conv module's
+    post-op, modules replaced by Identity, unfuse restores them."""
+    import utils.conv2d_func as cf
+    from cnns_slfp_quantization_amd import fusion
+    C = cf.conv2d_Q(32, 0.1, 0.2)
+    Cb = cf.conv2d_Q_bias(32, 0.1, 0.2)
+    m = nn.Sequential(C(8, 16, 3, 0.1, 0.2, 1, 1), nn.BatchNorm2d(16), nn.ReLU(inplace=True),
+                      Cb(16, 16, 1, 0.1, 0.2), nn.BatchNorm2d(16),
+                      C(16, 6, 1, 0.1, 0.2), nn.BatchNorm2d(6), nn.ReLU()).eval()   # 6 channels: not fusable (% 4)
+    for b in (m[1], m[4], m[6]):
+        b.running_mean.normal_(); b.running_var.uniform_(0.5, 1.5); b.weight.data.uniform_(0.5, 1.5); b.bias.data.normal_()
+    x = torch.randn(2, 8, 6, 6)
+    with torch.no_grad():
+        y0 = m(x)
+        assert fusion.fuse_bn_relu(m) == 2
+        assert [type(c).__name__ for c in m] == ["Conv2d_Q", "Identity", "Identity", "Conv2d_Q", "Identity", "Conv2d_Q", "BatchNorm2d", "ReLU"]
+        assert m[0]._post[2] is True and m[3]._post[2] is False
+        y1 = m(x)
+        assert torch.allclose(y0, y1, rtol=1e-5, atol=1e-5)
+        assert fusion.unfuse(m) == 2 and isinstance(m[1], nn.BatchNorm2d) and m[0]._post is None
+        assert torch.equal(m(x), y0)
+    m.train()
+    with pytest.raises(RuntimeError):
+        fusion.fold_bn(m[1])  # training-mode BN cannot be folded

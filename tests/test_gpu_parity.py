@@ -449,3 +449,56 @@ def test_all_layer_geometries_of_reference_nets(lib, dev, net):
         emax, el2 = rel_errors(got, ref)
         assert emax <= tol and el2 <= tol, (net, li, key, kern, emax, el2)
     assert len(seen) >= 3 and kernels
+
+
+# ------------------------------------------------------------------ fused eval-BN + ReLU epilogue
+def test_fused_bn_relu_epilogue_matches_stock_modules(dev):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import netgen
+    import utils.conv2d_func as cf
+    from cnns_slfp_quantization_amd import fusion, layer_specs
+    # (1) one Sequential per kernel family: stem, dw (s1/s2), pointwise stream + tiled, direct, bias variant
+    Ka, Kw = np.float64(0.17), np.float64(0.12)
+    C, Cb = cf.conv2d_Q(8, Kw, Ka), cf.conv2d_Q_bias(8, Kw, Ka)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    cases = [(C(3, 32, 3, Kw, Ka, 2, 1), 3, 33), (C(64, 64, 3, Kw, Ka, 1, 1, groups=64), 64, 20),
+             (C(64, 64, 3, Kw, Ka, 2, 1, groups=64), 64, 21), (C(64, 128, 1, Kw, Ka), 64, 14), (C(256, 512, 1, Kw, Ka), 256, 9),
+             (C(16, 32, 3, Kw, Ka, 1, 1), 16, 12), (Cb(16, 32, 3, Kw, Ka, 1, 1), 16, 12)]
+    try:
+        for passes in (3, 0):
+            cf.options.mfma_passes = passes
+            for conv, cin, hw in cases:
+                seq = torch.nn.Sequential(conv, torch.nn.BatchNorm2d(conv.out_channels), torch.nn.ReLU(inplace=True)).to(dev).eval()
+                bn = seq[1]
+                with torch.no_grad():
+                    conv.weight.copy_((torch.randn(conv.weight.shape, generator=g) * 0.4).to(dev))
+                    bn.running_mean.copy_((torch.randn(bn.num_features, generator=g) * 0.3).to(dev))
+                    bn.running_var.copy_((torch.rand(bn.num_features, generator=g) + 0.5).to(dev))
+                    bn.weight.copy_((torch.rand(bn.num_features, generator=g) + 0.5).to(dev))
+                    bn.bias.copy_((torch.randn(bn.num_features, generator=g) * 0.2).to(dev))
+                    x = (torch.randn((3, cin, hw, hw), generator=g) * 0.8).to(dev).contiguous(memory_format=torch.channels_last)
+                    y0 = seq(x)
+                    assert fusion.fuse_bn_relu(seq) == 1
+                    y1 = seq(x)
+                    assert isinstance(seq[1], torch.nn.Identity) and isinstance(seq[2], torch.nn.Identity)
+                e = rel_errors(y1.cpu().numpy(), y0.cpu().numpy())
+                assert max(e) <= 2e-6, (conv._last_kernel, e)   # same conv result; BN as one fma instead of stock BN
+                assert float(y1.min()) >= 0.0
+                fusion.unfuse(seq)
+        # (2) the whole CIFAR MobileNetV1 (config 1): fused logits == unfused logits, and still on the golden
+        gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "net_golden.npz"))
+        rows = layer_specs.nets()["mobilenetv1_cifar32"]["layers"]
+        scales = [(r["Ka"], r["Kw"]) for r in rows]
+        cf.options.mfma_passes = 3
+        m = netgen.fill_parameters(netgen.build_mobilenetv1_cifar(cf.conv2d_Q, cf.linear_Q, 8, scales)).to(dev).eval()
+        m = m.to(memory_format=torch.channels_last)
+        x = netgen.net_input().to(dev).contiguous(memory_format=torch.channels_last)
+        with torch.no_grad():
+            l0 = m(x)
+            assert fusion.fuse_bn_relu(m) == 27
+            l1 = m(x)
+        assert max(rel_errors(l1.cpu().numpy(), l0.cpu().numpy())) <= 2e-3   # chained requantization amplifies 1e-7 differences
+        assert max(rel_errors(l1.cpu().numpy(), gold["logits_q8"])) <= 4e-3
+    finally:
+        cf.options.mfma_passes = 0
