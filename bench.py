@@ -96,6 +96,49 @@ def pmc_traffic(family):
     return (int(tot / n), os.path.basename(files[-1]).replace("_summary.json", "")) if n else (None, None)
 
 
+def whole_net(specs, net, batch, dev, steps):
+    """Secondary, clearly labelled number: the whole MobileNetV1 through this repo's
+    drop-in modules INCLUDING the stock nn.BatchNorm2d / nn.ReLU / AvgPool2d / Linear between
+    and after the convs (nets_imgnet/mobilenetv1.py:43-61), channels_last, eval, no_grad -- and
+    the same net after fusion.fuse_bn_relu (eval-BN + ReLU folded into the conv epilogues)."""
+    import torch.nn as nn
+    import utils.conv2d_func as cf
+    from cnns_slfp_quantization_amd import fusion
+    if net != "mobilenetv1_imagenet224":
+        return None
+    layers = []
+    for s in specs:
+        conv = cf.conv2d_Q(q_bit=8, Kw=np.float64(s.Kw), Ka=np.float64(s.Ka))(
+            s.c_in, s.c_out, s.k[0], np.float64(s.Kw), np.float64(s.Ka), s.stride[0], s.pad[0], groups=s.groups, bias=False)
+        layers += [conv, nn.BatchNorm2d(s.c_out), nn.ReLU(inplace=True)]
+    model = nn.Sequential(*layers, nn.AvgPool2d(7), nn.Flatten(), nn.Linear(1024, 1000)).to(dev).eval()
+    g = torch.Generator(device=dev).manual_seed(3)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.running_var.uniform_(0.5, 1.5, generator=g)
+                m.weight.uniform_(0.8, 1.6, generator=g)
+                m.bias.normal_(0.1, 0.1, generator=g)
+    model = model.to(memory_format=torch.channels_last)
+    x = torch.randn((batch, 3, 224, 224), device=dev, generator=g).contiguous(memory_format=torch.channels_last)
+    out = {}
+    with torch.no_grad():
+        for tag in ("stock_bn_relu", "fused_bn_relu"):
+            if tag == "fused_bn_relu":
+                fusion.fuse_bn_relu(model)
+            for _ in range(2):
+                model(x)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                model(x)
+            torch.cuda.synchronize()
+            out[tag] = round(batch * steps / (time.perf_counter() - t0), 1)
+    out["unit"] = "images/sec"
+    out["note"] = "whole MobileNetV1-224 incl. BN/ReLU/pool/fc through the drop-in modules, 1 GPU, batch %d" % batch
+    return out
+
+
 def cpu_baseline(specs, sample_batch, iters):
     """The reference's CPU path re-stated with the same ATen op sequence (oracle/torch_port.py,
     proven bit-identical to the reference in the build container), timed on this box's
@@ -141,6 +184,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
     ap.add_argument("--passes", type=int, default=0, choices=[0, 1, 3], help="pointwise MFMA precision (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-whole-net", action="store_true")
     ap.add_argument("--cpu-sample-batch", type=int, default=16)
     ap.add_argument("--per-layer", action="store_true", help="also print a per-layer table to stderr")
     args = ap.parse_args()
@@ -274,6 +318,12 @@ def main():
                 s = l.spec
                 print(f"  {l.kernel:18s} {s.c_in:4d}->{s.c_out:4d} k{s.k[0]} s{s.stride[0]} {s.h:3d}->{s.h_out:3d}  "
                       f"{ms:8.4f} ms  {l.bytes / ms / 1e6:8.1f} GB/s", file=sys.stderr)
+        if world == 1 and not args.no_whole_net:
+            del layers  # free the per-layer workload buffers first
+            torch.cuda.empty_cache()
+            wn = whole_net(specs, args.net, args.batch, dev, max(3, args.steps // 2))
+            if wn:
+                out["whole_net"] = wn
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(specs, args.cpu_sample_batch, 1)
         print(json.dumps(out), flush=True)
