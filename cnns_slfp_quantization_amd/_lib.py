@@ -18,7 +18,7 @@ MFMA_DEFAULT, MFMA_F16X1, MFMA_F16X3 = 0, 1, 3
 # every symbol include/slfp.h declares (tests check the .so exports exactly these)
 SYMBOLS = (
     "slfp_version", "slfp_last_error", "slfp_device_count",
-    "slfp_encode_f32", "slfp_decode_f32", "slfp_quantize_f32",
+    "slfp_encode_f32", "slfp_decode_f32", "slfp_quantize_f32", "slfp_quantize_layerout_f32", "slfp_absmax_f32",
     "slfp_conv2d_out_shape", "slfp_conv2d_kernel_name", "slfp_conv2d_wprep_bytes",
     "slfp_conv2d_prepare_weights", "slfp_conv2d_workspace_bytes", "slfp_conv2d_fwd", "slfp_conv2d_fwd_post",
     "slfp_linear_workspace_bytes", "slfp_linear_fwd",
@@ -67,6 +67,8 @@ def load():
         "slfp_encode_f32": (ci, [vp, vp, sz, cf, ci, vp]),
         "slfp_decode_f32": (ci, [vp, vp, sz, ci, vp]),
         "slfp_quantize_f32": (ci, [vp, vp, sz, cf, ci, vp]),
+        "slfp_quantize_layerout_f32": (ci, [vp, vp, sz, vp]),
+        "slfp_absmax_f32": (ci, [vp, sz, vp, vp]),
         "slfp_conv2d_out_shape": (ci, [dp, ctypes.POINTER(i64), ctypes.POINTER(i64)]),
         "slfp_conv2d_kernel_name": (ctypes.c_char_p, [dp]),
         "slfp_conv2d_wprep_bytes": (sz, [dp]),

@@ -96,6 +96,58 @@ __global__ __launch_bounds__(kThreads) void k_decode(const uint8_t* __restrict__
         y[i] = __uint_as_float(decode_bits<FMT>(code[i], ext, sT));
 }
 
+// quantize_layerout(k <= 8).forward (utils/sfp_quant.py:108-127): SFP<4,4> layer-output quantizer.
+// The reference's `2^(-8)` is integer XOR, so only three things are live: RNE to 5 significant
+// bits at every exponent (denormals included), the >= 248 clamp, and NaN for an exact zero.
+__device__ __forceinline__ uint32_t layerout_bits(uint32_t u) {
+    const uint32_t a = u & 0x7FFFFFFFu, s = u & 0x80000000u;
+    uint32_t v = (a + 0x3FFFFu + ((a >> 19) & 1u)) & 0xFFF80000u;
+    if (a < 0x00800000u && a != 0u) {  // denormal: keep 5 significant bits (rare path)
+        const int p = 31 - __clz((int)a);
+        const int sh = p > 4 ? p - 4 : 0;
+        v = sh > 0 ? ((a + ((1u << (sh - 1)) - 1u) + ((a >> sh) & 1u)) >> sh) << sh : a;
+    }
+    v = a >= 0x43780000u ? 0x43780000u : v;  // >= 248 -> 248
+    v |= s;
+    v = (a == 0u || a > 0x7F800000u) ? kBitsQNaN : v;  // 0 * inf in the reference; NaN in -> NaN out
+    return v;
+}
+
+__global__ __launch_bounds__(kThreads) void k_layerout(const float* __restrict__ x, float* __restrict__ y, size_t n, int vec_ok) {
+    const size_t nvec = vec_ok ? n / 4 : 0;
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += stride) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        float4 r;
+        r.x = __uint_as_float(layerout_bits(__float_as_uint(v.x)));
+        r.y = __uint_as_float(layerout_bits(__float_as_uint(v.y)));
+        r.z = __uint_as_float(layerout_bits(__float_as_uint(v.z)));
+        r.w = __uint_as_float(layerout_bits(__float_as_uint(v.w)));
+        reinterpret_cast<float4*>(y)[i] = r;
+    }
+    for (size_t i = nvec * 4 + (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride)
+        y[i] = __uint_as_float(layerout_bits(__float_as_uint(x[i])));
+}
+
+// max |x| over a tensor (the per-layer calibration statistic of get_scale_factor,
+// cifar100_train_eval.py:261-271): wave64 shuffle reduction, one atomicMax per wave on the
+// float bits (non-negative floats order like unsigned integers).  *out must be zeroed first.
+__global__ __launch_bounds__(kThreads) void k_absmax(const float* __restrict__ x, uint32_t* __restrict__ out, size_t n, int vec_ok) {
+    const size_t nvec = vec_ok ? n / 4 : 0;
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    uint32_t m = 0;
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += stride) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        m = max(max(m, __float_as_uint(v.x) & 0x7FFFFFFFu), __float_as_uint(v.y) & 0x7FFFFFFFu);
+        m = max(max(m, __float_as_uint(v.z) & 0x7FFFFFFFu), __float_as_uint(v.w) & 0x7FFFFFFFu);
+    }
+    for (size_t i = nvec * 4 + (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride)
+        m = max(m, __float_as_uint(x[i]) & 0x7FFFFFFFu);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
 static int grid_for(size_t n) {
     size_t blocks = (n / 4 + kThreads - 1) / kThreads;
     if (blocks < 1) blocks = 1;
@@ -220,6 +272,24 @@ int slfp_decode_f32(const uint8_t* code, float* y, size_t n, int fmt, void* stre
     else if (f == kFmtAct8 || f == kFmtW8) hipLaunchKernelGGL((k_decode<kFmtAct8>), dim3(g), dim3(kThreads), 0, st, code, y, n, ext, vec_ok);
     else return fail(SLFP_ERR_BAD_ARG, "unknown codec format %d", fmt);
     return check_launch("slfp decode kernel");
+}
+
+int slfp_quantize_layerout_f32(const float* x, float* y, size_t n, void* stream) {
+    if (n == 0) return SLFP_OK;
+    if (!x || !y) return fail(SLFP_ERR_BAD_ARG, "slfp_quantize_layerout_f32: null pointer");
+    const int vec_ok = aligned16(x) && aligned16(y);
+    hipLaunchKernelGGL(k_layerout, dim3(grid_for(n)), dim3(kThreads), 0, as_stream(stream), x, y, n, vec_ok);
+    return check_launch("slfp layerout kernel");
+}
+
+int slfp_absmax_f32(const float* x, size_t n, float* out, void* stream) {
+    if (!out) return fail(SLFP_ERR_BAD_ARG, "slfp_absmax_f32: null pointer");
+    hipStream_t st = as_stream(stream);
+    if (hipMemsetAsync(out, 0, sizeof(float), st) != hipSuccess) return check_launch("hipMemsetAsync(absmax)");
+    if (n == 0) return SLFP_OK;
+    if (!x) return fail(SLFP_ERR_BAD_ARG, "slfp_absmax_f32: null pointer");
+    hipLaunchKernelGGL(k_absmax, dim3(grid_for(n)), dim3(kThreads), 0, st, x, reinterpret_cast<uint32_t*>(out), n, (int)aligned16(x));
+    return check_launch("slfp absmax kernel");
 }
 
 int slfp_debug_div_mismatches(float scale_div, unsigned long long* out2, void* stream) {

@@ -111,13 +111,51 @@ class _LayeroutSTE(torch.autograd.Function):
         return g.clone()
 
 
+class _LayeroutHip(torch.autograd.Function):
+    """The same quantizer as ONE HIP pass (slfp_quantize_layerout_f32), bit-identical to the
+    reference (tests/golden: all denormals + sampled binades); STE backward (:129-132)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        L = _lib.load()
+        dense = x.is_contiguous() or (x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last))
+        src = x if dense else x.contiguous()
+        y = torch.empty_like(src)
+        with torch.cuda.device(x.device):
+            _lib.check(L.slfp_quantize_layerout_f32(src.data_ptr(), y.data_ptr(), src.numel(), _stream_handle(x)))
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.clone()
+
+
+def _layerout_dispatch(x):
+    # ROCm float32 tensors take the HIP kernel; anything else the plain-PyTorch mirror above
+    if x.is_cuda and x.dtype == torch.float32:
+        return _LayeroutHip.apply(x)
+    return _LayeroutSTE.apply(x)
+
+
 def quantize_layerout(k):
     """utils/sfp_quant.py:105-133 (k <= 8 -> SFP<4,4>, 32 -> identity)."""
     if k == 32:
         return lambda x: x
     if k > 8:
         raise ValueError(f"q_bit must be <= 8 or 32, got {k}")
-    return _LayeroutSTE.apply
+    return _layerout_dispatch
+
+
+def absmax(x):
+    """max |x| as a 0-dim tensor on x's device (HIP wave-shuffle reduction): the statistic the
+    reference's calibration pass takes per layer (cifar100_train_eval.py:261-271)."""
+    _require_gpu_f32(x, "slfp absmax")
+    L = _lib.load()
+    src = x if x.is_contiguous() or (x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)) else x.contiguous()
+    out = torch.empty((), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(L.slfp_absmax_f32(src.data_ptr(), src.numel(), out.data_ptr(), _stream_handle(x)))
+    return out
 
 
 class _QuantModule(nn.Module):

@@ -72,6 +72,14 @@ int slfp_decode_f32(const uint8_t* code, float* y, size_t n, int fmt, void* stre
  * (utils/sfp_quant.py:10-48, :59-97).  x == y (in place) is allowed. */
 int slfp_quantize_f32(const float* x, float* y, size_t n, float scale_div, int fmt, void* stream);
 
+/* y[i] = SFP<4,4> layer-output quantizer: replaces quantize_layerout(k <= 8).forward
+ * (utils/sfp_quant.py:108-127), bit-identical including its quirks (the reference's `2^(-8)` is an
+ * integer XOR, so only RNE to 5 significant bits, the >= 248 clamp and NaN-for-exact-zero are live). */
+int slfp_quantize_layerout_f32(const float* x, float* y, size_t n, void* stream);
+/* *out = max_i |x[i]| (device pointer to one float32): the per-layer statistic of the reference's
+ * calibration pass get_scale_factor (cifar100_train_eval.py:261-271); Ka = max / 15.5. */
+int slfp_absmax_f32(const float* x, size_t n, float* out, void* stream);
+
 /* ---- conv2d: replaces Conv2d_Q.forward (utils/conv2d_func.py:20-25 and :41-47) ------ */
 
 typedef struct slfp_conv2d_desc {

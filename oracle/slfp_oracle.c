@@ -276,4 +276,34 @@ int slfp_oracle_linear(const float* x, int64_t B, int64_t I, const float* w, int
     return 0;
 }
 
+/*
+ * quantize_layerout(k <= 8).forward  (utils/sfp_quant.py:108-127), the SFP<4,4> layer-output
+ * quantizer.  In the reference `2^(-8)` / `2^(-7)` parse as integer XOR (= -6 / -5), so its two
+ * "subnormal" overrides never fire: what is left is RNE to 5 significant bits at EVERY exponent
+ * (denormals included), the `>= 248 -> 248` clamp, and NaN for an exact zero (0 * inf).  Pinned
+ * against the imported reference by tests/golden/make_golden.py (all denormals + sampled binades).
+ */
+void slfp_oracle_layerout(const float* x, float* y, size_t n) {
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; ++i) {
+        const uint32_t u = f2u(x[i]);
+        const uint32_t a = u & 0x7FFFFFFFu, s = u & 0x80000000u;
+        uint32_t v;
+        if (a > 0x7F800000u || a == 0) {
+            v = BITS_QNAN;
+        } else if (a >= 0x43780000u) {
+            v = s | 0x43780000u; /* 248 */
+        } else if (a >= 0x00800000u) {
+            v = s | ((a + 0x3FFFFu + ((a >> 19) & 1u)) & 0xFFF80000u);
+        } else { /* denormal: keep 5 significant bits */
+            int p = 31 - __builtin_clz(a);
+            int sh = p > 4 ? p - 4 : 0;
+            uint32_t r = a;
+            if (sh > 0) r = ((a + ((1u << (sh - 1)) - 1u) + ((a >> sh) & 1u)) >> sh) << sh;
+            v = s | r;
+        }
+        y[i] = u2f(v);
+    }
+}
+
 int slfp_oracle_version(void) { return 1; }

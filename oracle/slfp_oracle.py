@@ -37,6 +37,8 @@ def lib():
         L.slfp_oracle_quantize.restype = None
         L.slfp_oracle_encode.argtypes = [fp, bp, ctypes.c_size_t, ctypes.c_float, ctypes.c_int]
         L.slfp_oracle_encode.restype = None
+        L.slfp_oracle_layerout.argtypes = [fp, fp, ctypes.c_size_t]
+        L.slfp_oracle_layerout.restype = None
         L.slfp_oracle_decode.argtypes = [bp, fp, ctypes.c_size_t, ctypes.c_int]
         L.slfp_oracle_decode.restype = None
         i64, ci = ctypes.c_int64, ctypes.c_int
@@ -68,6 +70,14 @@ def quantize(x, scale_div, fmt):
     x = _f32(x)
     y = np.empty_like(x)
     lib().slfp_oracle_quantize(_p(x), _p(y), x.size, np.float32(scale_div), fmt)
+    return y
+
+
+def layerout(x):
+    """quantize_layerout(k <= 8).forward (utils/sfp_quant.py:108-127), SFP<4,4> with the reference's quirks."""
+    x = _f32(x)
+    y = np.empty_like(x)
+    lib().slfp_oracle_layerout(_p(x), _p(y), x.size)
     return y
 
 

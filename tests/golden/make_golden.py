@@ -36,7 +36,7 @@ import torch  # noqa: E402
 from oracle import slfp_oracle as so  # noqa: E402
 from oracle import torch_port as tp  # noqa: E402
 from utils.conv2d_func import conv2d_Q, conv2d_Q_bias, linear_Q  # noqa: E402  (reference)
-from utils.sfp_quant import quantize_act, quantize_weight  # noqa: E402  (reference)
+from utils.sfp_quant import quantize_act, quantize_layerout, quantize_weight  # noqa: E402  (reference)
 
 assert "/root/reference" in sys.modules["utils.sfp_quant"].__file__, "must import the REFERENCE utils"
 
@@ -131,6 +131,26 @@ def make_codec(report, rng):
         assert same_bits(r, c), f"oracle mismatch on fixture inputs for {name}"
         out[name + "_in_bits"] = bits
         out[name + "_out_bits"] = r
+    # SFP<4,4> layer-output quantizer (sfp_quant.py:105-133): pin the oracle on every denormal, on a
+    # full binade around 1 and 248, and on 2^14 samples of every other binade; then store a fixture
+    lo = quantize_layerout(8)
+    bad = 0
+    starts = list(range(0, 0x00800000, 1 << 22)) + [0x3F800000, 0x43000000]
+    for st in starts:
+        bits = np.arange(st, st + (1 << 22 if st < 0x00800000 else 1 << 23), dtype=np.uint32)
+        bad += int(not same_bits(ref_bits(lo, bits), so.layerout(bits.view(np.float32)).view(np.uint32)))
+    for e in range(1, 255):
+        bits = (np.uint32(e << 23) + rng.integers(0, 1 << 23, 1 << 14, dtype=np.uint64).astype(np.uint32))
+        bits = np.concatenate([bits, bits | np.uint32(0x80000000)])
+        bad += int(not same_bits(ref_bits(lo, bits), so.layerout(bits.view(np.float32)).view(np.uint32)))
+    assert bad == 0, "oracle layerout does not match the reference"
+    mids = (np.arange(0x3F800000, 0x43800000, 1 << 19, dtype=np.int64)[:, None] + 0x40000 + np.arange(-2, 3)[None, :]).reshape(-1)
+    lbits = np.concatenate([edge_inputs().view(np.uint32), mids.astype(np.uint32), (mids.astype(np.uint32) | np.uint32(0x80000000)),
+                            np.arange(1, 300, dtype=np.uint32), rng.integers(0, 1 << 32, 30000, dtype=np.uint64).astype(np.uint32),
+                            (np.exp2(rng.uniform(-12, 9, 30000)).astype(np.float32) * rng.choice([-1.0, 1.0], 30000).astype(np.float32)).view(np.uint32)])
+    out["layerout_in_bits"] = lbits
+    out["layerout_out_bits"] = ref_bits(lo, lbits)
+    assert same_bits(out["layerout_out_bits"], so.layerout(lbits.view(np.float32)).view(np.uint32))
     # scaled division: the operator divides by a float64 0-dim tensor (conv2d_func.py:21-22)
     ka64 = np.array([2.6023073196411133, 13.16812801361084, 1.7093303203582764, 9.842595100402832]) / 15.5
     xs = (rng.standard_normal(30000) * 3.0).astype(np.float32)

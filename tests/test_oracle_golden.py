@@ -150,3 +150,13 @@ def test_live_reference_agrees_with_oracle():
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_layerout_golden(codec_golden):
+    """SFP<4,4> layer-output quantizer (utils/sfp_quant.py:105-133) incl. its quirks: the reference's
+    2^(-8) is an XOR, so exact zeros come out NaN and tiny values are rounded, not flushed."""
+    x = codec_golden["layerout_in_bits"].view(np.float32)
+    assert same_bits(so.layerout(x), codec_golden["layerout_out_bits"])
+    y = so.layerout(np.array([0.3, 1.03, 300.0, -500.0, 0.0, 247.9, 1e-40], np.float32))
+    assert y[0] == np.float32(0.296875) and y[1] == 1.0 and y[2] == 248.0 and y[3] == -248.0 and np.isnan(y[4]) and y[5] == 248.0
+    assert 0 < y[6] < 1.1e-40
