@@ -8,5 +8,7 @@ conv2d forward path behind the operator API of happyxtt/CNNs_SLFP_quantization.
     activation_func.py  mirror of utils/activation_func.py (outside the hot path)
     layer_specs.py   Conv2d_Q layer tables of the reference nets (shapes + calibration scales)
     sharding.py      batch-axis sharding + one-time weight broadcast (torch.distributed / RCCL)
+    fusion.py        eval-BN + ReLU folded into the conv epilogues
+    calibration.py   device-side max|.| statistics for Ka / Kw
 """
 __version__ = "0.1.0"

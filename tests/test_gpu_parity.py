@@ -524,3 +524,20 @@ def test_layerout_quantizer_and_absmax(lib, dev, codec_golden):
         assert float(absmax(t[1:])) == (77.5 if n > 2 else float(t[1:].abs().max()) if n > 1 else 0.0)
     a = torch.randn(2, 8, 5, 5, device=dev).contiguous(memory_format=torch.channels_last)
     assert float(absmax(a)) == float(a.abs().max())
+
+
+def test_device_side_calibration(dev):
+    import utils.conv2d_func as cf
+    from cnns_slfp_quantization_amd import calibration
+    C = cf.conv2d_Q(32, 1.0, 1.0)
+    m = torch.nn.Sequential(C(3, 8, 3, 1.0, 1.0, 1, 1), torch.nn.ReLU(), C(8, 8, 1, 1.0, 1.0), torch.nn.Flatten(),
+                            cf.linear_Q(32, 1.0, 1.0)(8 * 36, 5)).to(dev).eval()
+    g = torch.Generator(device=dev).manual_seed(2)
+    batches = [torch.randn(4, 3, 6, 6, generator=g, device=dev) * (i + 1) for i in range(4)]
+    mi, mw = calibration.collect_max_abs(m, batches, total_images=12)  # stops after 3 batches
+    with torch.no_grad():
+        ref_in0 = max(float(b.abs().max()) for b in batches[:3])
+        ref_in1 = max(float(torch.relu(m[0](b)).abs().max()) for b in batches[:3])
+    assert mi[0] == ref_in0 and abs(mi[1] - ref_in1) <= 1e-6 * ref_in1 and len(mi) == 3
+    assert mw[0] == float(m[0].weight.detach().abs().max()) and mw[2] == float(m[4].weight.detach().abs().max())
+    assert calibration.scales_from_max(mw)[0] == mw[0] / 15.5
