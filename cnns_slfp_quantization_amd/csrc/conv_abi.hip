@@ -53,6 +53,11 @@ int make_plan(const slfp_conv2d_desc* d, ConvPlan* plan) {
         plan->k_pad = ceil_div(d->c_in, 64) * 64;
         plan->n_pad = ceil_div(d->c_out, 64) * 64;
         plan->wprep_bytes = round256((size_t)2 * plan->k_pad * plan->n_pad * sizeof(_Float16));
+    } else if (dense_mfma_applicable(*d, plan->passes)) {
+        plan->family = kDenseMfma;
+        plan->k_pad = ceil_div(d->c_in, 64) * 64;
+        plan->n_pad = ceil_div(d->c_out, 16) * 16;
+        plan->wprep_bytes = round256((size_t)d->kh * d->kw * plan->k_pad * plan->n_pad * sizeof(_Float16));
     } else {
         plan->family = kDirect;
         plan->wprep_bytes = round256((size_t)d->kh * d->kw * cg * d->c_out * sizeof(float));
@@ -82,6 +87,13 @@ __global__ __launch_bounds__(256) void k_prepare(const float* __restrict__ w, vo
         reinterpret_cast<float*>(prep)[(size_t)(kh * 3 + kw) * O + o] = q;  // [9][C]
     } else if (family == kDirect) {
         reinterpret_cast<float*>(prep)[((size_t)(kh * KW + kw) * Cg + ci) * O + o] = q;  // [KH][KW][Cg][O]
+    } else if (family == kDenseMfma) {
+        // tap-major copy of the pointwise fragment order (single fp16 plane): conv_dense.hip
+        const int nt = o >> 4, row = o & 15, ks = ci >> 5, kk = ci & 31;
+        const int kq = (kk & 15) >> 2, j = (kk >> 4) * 4 + (kk & 3);
+        const size_t ntiles = (size_t)(plane / ((int64_t)KS * 32 * 16));
+        const size_t at = ((((size_t)(kh * KW + kw) * ntiles + nt) * KS + ks) * 64 + (size_t)(kq * 16 + row)) * 8 + j;
+        reinterpret_cast<_Float16*>(prep)[at] = (_Float16)(16.0f * q);
     } else {
         // MFMA 16x16x32 A-fragment order: tile (o/16, k/32), lane = kq*16 + o%16 where lane-quarter kq
         // holds k%32 in {kq*4..kq*4+3} (elements 0-3) and {16+kq*4..16+kq*4+3} (elements 4-7): conv_pw.hip
@@ -100,7 +112,7 @@ int launch_prepare_weights(const slfp_conv2d_desc& d, const ConvPlan& p, const f
                            float* weight_q_oihw, hipStream_t stream) {
     const int Cg = (int)(d.c_in / d.groups);
     const int64_t total = d.c_out * Cg * d.kh * d.kw;
-    if (p.family == kPointwise) {
+    if (p.family == kPointwise || p.family == kDenseMfma) {
         if (hipMemsetAsync(wprep, 0, p.wprep_bytes, stream) != hipSuccess) return check_launch("hipMemsetAsync(wprep)");
     }
     const int64_t plane = p.k_pad * p.n_pad;
@@ -121,6 +133,7 @@ static const char* family_name(const ConvPlan& p, const slfp_conv2d_desc& d) {
     switch (p.family) {
         case kDw3x3: return "dw3x3_nhwc";
         case kPointwise: return p.fmt_act == kFmtSfp7 ? "pw_mfma_f16_exact" : (p.passes == 3 ? "pw_mfma_f16x3" : "pw_mfma_f16x1");
+        case kDenseMfma: return p.fmt_act == kFmtSfp7 ? "dense_mfma_f16_exact" : "dense_mfma_f16x1";
         default: return "direct_nhwc";
     }
 }
@@ -212,6 +225,7 @@ int slfp_conv2d_fwd_post(const slfp_conv2d_desc* d, const float* x, const void* 
     switch (p.family) {
         case kDw3x3: rc = launch_dw3x3(*d, p, x_nhwc, reinterpret_cast<const float*>(wprep), bias, post, y_nhwc, st); break;
         case kPointwise: rc = launch_pointwise(*d, p, x_nhwc, wprep, bias, post, y_nhwc, st); break;
+        case kDenseMfma: rc = launch_dense_mfma(*d, p, x_nhwc, wprep, bias, post, y_nhwc, st); break;
         default: rc = launch_direct(*d, p, x_nhwc, reinterpret_cast<const float*>(wprep), bias, post, y_nhwc, st); break;
     }
     if (rc != SLFP_OK) return rc;

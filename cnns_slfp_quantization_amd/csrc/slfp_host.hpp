@@ -33,7 +33,7 @@ inline ScaleDiv make_scale_div(float d, int esh = 0) {
 }
 
 // Kernel families (slfp_conv2d_kernel_name reports them).
-enum KernelFamily { kDw3x3 = 0, kPointwise = 1, kDirect = 2 };
+enum KernelFamily { kDw3x3 = 0, kPointwise = 1, kDirect = 2, kDenseMfma = 3 };
 
 struct ConvPlan {
     KernelFamily family;
@@ -59,6 +59,10 @@ int launch_pointwise(const slfp_conv2d_desc& d, const ConvPlan& p, const float* 
 int launch_direct(const slfp_conv2d_desc& d, const ConvPlan& p, const float* x, const float* wq_hwio,
                   const float* bias, const PostOp& post, float* y, hipStream_t stream);
 bool stem_applicable(const slfp_conv2d_desc& d);  // direct family: the small-C_in stem kernel takes it
+// dense k x k implicit GEMM on MFMA (conv_dense.hip); wblob = [tap][n_tile][k_step][64][8] fp16
+bool dense_mfma_applicable(const slfp_conv2d_desc& d, int passes);
+int launch_dense_mfma(const slfp_conv2d_desc& d, const ConvPlan& p, const float* x, const void* wblob,
+                      const float* bias, const PostOp& post, float* y, hipStream_t stream);
 int launch_prepare_weights(const slfp_conv2d_desc& d, const ConvPlan& p, const float* w_oihw, void* wprep,
                            float* weight_q_oihw, hipStream_t stream);
 

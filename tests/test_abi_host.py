@@ -47,7 +47,15 @@ def test_kernel_selection_and_sizes():
     pw.qbits = 7
     assert name(pw) == "pw_mfma_f16_exact"                                       # SFP<3,3> is exact in fp16
     assert name(_desc(c_in=3, c_out=32, groups=1, stride_h=2, stride_w=2)) == "stem_nhwc"
-    assert name(_desc(c_in=16, c_out=32, groups=1)) == "direct_nhwc"
+    dense = _desc(c_in=16, c_out=32, groups=1)
+    assert name(dense) == "dense_mfma_f16x1"                                     # dense k x k: implicit GEMM on MFMA
+    assert L.slfp_conv2d_wprep_bytes(ctypes.byref(dense)) == 9 * 64 * 32 * 2     # [tap][C_in pad 64][C_out pad 16] fp16
+    dense.mfma_passes = _lib.MFMA_F16X3
+    assert name(dense) == "direct_nhwc"                                          # float32-equivalent mode: fp32 kernel
+    dense.qbits = 7
+    assert name(dense) == "dense_mfma_f16_exact"
+    assert name(_desc(c_in=8, c_out=32, groups=1)) == "direct_nhwc"               # too few channels for a k-step
+    assert name(_desc(c_in=16, c_out=32, groups=1, dil_h=2, dil_w=2)) == "direct_nhwc"
     ho, wo = ctypes.c_int64(), ctypes.c_int64()
     assert L.slfp_conv2d_out_shape(ctypes.byref(_desc(h=224, w=224, c_in=3, c_out=32, groups=1, stride_h=2, stride_w=2)),
                                    ctypes.byref(ho), ctypes.byref(wo)) == 0
