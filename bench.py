@@ -60,6 +60,8 @@ class Layer:
         self.w.mul_(min(5.0 * s.Kw, 3.0 * (2.0 / fan) ** 0.5 + 2.0 * s.Kw))
         self.bias = torch.randn(s.c_out, generator=gen, device=dev) * 0.1 if s.bias else None
         self.blob = torch.empty(L.slfp_conv2d_wprep_bytes(ctypes.byref(self.desc)), dtype=torch.uint8, device=dev)
+        ws = L.slfp_conv2d_workspace_bytes(ctypes.byref(self.desc))  # dense k x k layers: input encoded once to fp16
+        self.ws = torch.empty(ws, dtype=torch.uint8, device=dev) if ws else None
         self.bytes = spec.algorithmic_bytes(batch)
 
     def prepare(self, L, stream):
@@ -69,14 +71,15 @@ class Layer:
     def run(self, L, stream):
         rc = L.slfp_conv2d_fwd(ctypes.byref(self.desc), self.x.data_ptr(), self.blob.data_ptr(),
                                self.bias.data_ptr() if self.bias is not None else None, self.y.data_ptr(),
-                               None, None, stream)
+                               None, self.ws.data_ptr() if self.ws is not None else None, stream)
         if rc != 0:
             _lib.check(rc)
 
 
 FAMILY_KERNELS = {"dw3x3_nhwc": ("k_dw3x3",), "stem_nhwc": ("k_stem",), "direct_nhwc": ("k_direct",),
                   "pw_mfma_f16x1": ("k_pw_stream", "k_pw_tiled"), "pw_mfma_f16x3": ("k_pw_stream", "k_pw_tiled"),
-                  "pw_mfma_f16_exact": ("k_pw_stream", "k_pw_tiled")}
+                  "pw_mfma_f16_exact": ("k_pw_stream", "k_pw_tiled"),
+                  "dense_mfma_f16x1": ("k_dense_mfma", "k_dense_encode"), "dense_mfma_f16_exact": ("k_dense_mfma", "k_dense_encode")}
 
 
 def pmc_traffic(family):

@@ -181,6 +181,7 @@ size_t slfp_conv2d_workspace_bytes(const slfp_conv2d_desc* d) {
     size_t b = 0;
     if (d->x_layout == SLFP_LAYOUT_NCHW) b += round256((size_t)d->n * d->c_in * d->h * d->w * sizeof(float));
     if (d->y_layout == SLFP_LAYOUT_NCHW) b += round256((size_t)d->n * d->c_out * p.h_out * p.w_out * sizeof(float));
+    if (p.family == kDenseMfma) b += dense_mfma_workspace_bytes(*d);  // the input encoded once to fp16
     return b;
 }
 
@@ -210,7 +211,7 @@ int slfp_conv2d_fwd_post(const slfp_conv2d_desc* d, const float* x, const void* 
     }
     const size_t ws_need = slfp_conv2d_workspace_bytes(d);
     if (ws_need && (!workspace || !aligned16(workspace)))
-        return fail(SLFP_ERR_BAD_ARG, "slfp_conv2d_fwd: %zu bytes of 16-byte aligned workspace required for NCHW", ws_need);
+        return fail(SLFP_ERR_BAD_ARG, "slfp_conv2d_fwd: %zu bytes of 16-byte aligned workspace required (slfp_conv2d_workspace_bytes)", ws_need);
     unsigned char* ws = reinterpret_cast<unsigned char*>(workspace);
     const float* x_nhwc = x;
     float* y_nhwc = y;
@@ -221,11 +222,14 @@ int slfp_conv2d_fwd_post(const slfp_conv2d_desc* d, const float* x, const void* 
         if (rc != SLFP_OK) return rc;
         x_nhwc = t;
     }
-    if (d->y_layout == SLFP_LAYOUT_NCHW) y_nhwc = reinterpret_cast<float*>(ws);
+    if (d->y_layout == SLFP_LAYOUT_NCHW) {
+        y_nhwc = reinterpret_cast<float*>(ws);
+        ws += round256((size_t)d->n * d->c_out * p.h_out * p.w_out * sizeof(float));
+    }
     switch (p.family) {
         case kDw3x3: rc = launch_dw3x3(*d, p, x_nhwc, reinterpret_cast<const float*>(wprep), bias, post, y_nhwc, st); break;
         case kPointwise: rc = launch_pointwise(*d, p, x_nhwc, wprep, bias, post, y_nhwc, st); break;
-        case kDenseMfma: rc = launch_dense_mfma(*d, p, x_nhwc, wprep, bias, post, y_nhwc, st); break;
+        case kDenseMfma: rc = launch_dense_mfma(*d, p, x_nhwc, wprep, bias, post, y_nhwc, ws, st); break;
         default: rc = launch_direct(*d, p, x_nhwc, reinterpret_cast<const float*>(wprep), bias, post, y_nhwc, st); break;
     }
     if (rc != SLFP_OK) return rc;

@@ -4,15 +4,18 @@
 // Replaces Conv2d_Q.forward (utils/conv2d_func.py:20-25 / :41-47) for groups == 1, KH*KW > 1.
 // These layers are compute-bound (VGG-16: 337 flop/B), so the contraction must run on MFMA; the
 // structure is the pointwise GEMM of conv_pw.hip with the K dimension = (tap, input channel):
-//   * workgroup = TH x 16 output pixels x 256 output channels, 8 waves (2 along rows x 4 along
-//     channels), accumulators MT x 4 tiles of 16x16 per wave;
+//   * workgroup = TH x 16 output pixels x BN output channels, 8 waves as WM (rows) x WN (channels),
+//     BN = 64 WN, TH = WM * MT; accumulators MT x 4 tiles of 16x16 per wave;
 //   * per 64-channel chunk the (TH-1)*S+KH x 15*S+KW input HALO tile is read once from HBM,
 //     x/Ka + SLFP encode applied inline, and stored as fp16 in a swizzled LDS tile: every one of
-//     the KH*KW taps then reads its shifted 16-pixel fragments from the same tile (the encode
-//     is amortised over KH*KW * 256 MACs per element);
-//   * per tap the 256 x 64 fp16 weight tile (fragment-ordered blob, tap-major) is staged in a
-//     double-buffered LDS tile by all waves (each fragment is used by both row-waves and by MT
-//     pixel tiles), one barrier per tap;
+//     the KH*KW taps then reads its shifted 16-pixel fragments from the same tile (the encode is
+//     amortised over KH*KW * BN MACs per element).  The NEXT chunk's halo is fetched in slices
+//     behind the taps' MFMAs, encoded as it lands and parked in registers (2 VGPRs per float4),
+//     then written over the single LDS tile between two barriers at the chunk boundary;
+//   * per tap the BN x 64 fp16 weight tile (fragment-ordered blob, tap-major) is brought in by
+//     LDS-DMA (global_load_lds, no VGPR staging) into a double buffer, one barrier per tap;
+//   * LDS footprint <= 80 KiB so that two workgroups share a CU: one's barrier / DMA wait is the
+//     other's MFMA time;
 //   * fp16 operands (both pre-scaled by 2^4, see conv_pw.hip), float32 accumulation, the
 //     reference's (out*Ka)*Kw roundings and the optional fused BN/ReLU post-op in the epilogue.
 // Single-pass fp16 (SLFP<3,4>: ~2.5e-4 tensor-relative, the north-star 1e-3 bar) or exact
@@ -27,22 +30,21 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 constexpr int kDnThreads = 512;
-constexpr int kDnTW = 16;            // output columns per tile = one MFMA pixel tile
-constexpr int kDnBN = 256;           // output channels per workgroup
-constexpr int kDnWBytes = kDnBN * 64 * 2;  // one tap's weight tile: 256 ch x 64 cin fp16 = 32 KiB
+constexpr int kDnTW = 16;  // output columns per tile = one MFMA pixel tile
 
 struct DenseParams {
-    const float* x;
+    const _Float16* xe;  // pre-encoded input, NHWC with C padded to Cp (k_dense_encode)
+    const unsigned char* zero_page;  // 256 zero bytes: DMA source for padding pixels / channels past Cp
     const _Float16* w;   // [tap][n_tile][k_step][64 lanes][8]
     const float* bias;
     float* y;
-    int N, H, W, C, O, KH, KW, S, ph, pw, Ho, Wo;
+    int N, H, W, Cp, O, KH, KW, S, ph, pw, Ho, Wo;
     int tiles_h, tiles_w, n_blocks;
     int IH, IW, n_pix;   // halo tile
     int KS;              // 32-deep k-steps per tap (c_pad / 32), even
     int n_tiles;         // 16-channel tiles in the blob (n_pad / 16)
-    int x_items_per_thread;  // ceil(n_pix * 16 float4 / 512 threads) per chunk
-    ScaleDiv sd;
+    int x_pieces;        // 1 KiB DMA pieces (8 halo pixels) per chunk = ceil(n_pix / 8)
+    int x_per_tap;       // pieces each wave issues per tap so that the next chunk is in by the last tap
     float s1, s2, s1x;
     PostOp post;
     uint32_t nblocks;
@@ -59,16 +61,47 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {  // 64 lanes x 
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-// MT = output rows per row-wave (TH = 2 * MT).  PER_TAP = halo float4 each thread prefetches per tap.
-template <int FMT, int MT, int PER_TAP>
-__global__ __launch_bounds__(kDnThreads) void k_dense_mfma(const DenseParams p) {
-    constexpr int TH = 2 * MT;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t* sT = reinterpret_cast<uint32_t*>(smem);
-    unsigned char* wbuf = smem + 64;                  // [2][kDnWBytes]
-    unsigned char* xsb = wbuf + 2 * kDnWBytes;        // [2][n_pix][128 B]
-    const uint32_t xbytes = (uint32_t)p.n_pix * 128u;
+// Pre-pass: x (float32 NHWC) -> xe = fp16(16 * QA(x / Ka)), NHWC with C padded to a multiple of 32
+// and, inside every 32-channel group, 16-byte chunk j = channels {4j..4j+3, 16+4j..16+4j+3}: exactly
+// the 8 k-values lane-quarter j of a 16x16x32 MFMA B fragment holds.  One thread per chunk.
+template <int FMT>
+__global__ __launch_bounds__(256) void k_dense_encode(const float* __restrict__ x, _Float16* __restrict__ xe,
+                                                      unsigned char* __restrict__ zero_page, int64_t n_chunks16,
+                                                      int C, int Cp, const ScaleDiv sd) {
+    __shared__ uint32_t sT[16];
     lut_fill<FMT>(sT);
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x < 16) reinterpret_cast<uint4*>(zero_page)[threadIdx.x] = make_uint4(0, 0, 0, 0);
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_chunks16) return;
+    const int per_pix = Cp >> 3;
+    const int64_t pix = idx / per_pix;
+    const int cj = (int)(idx - pix * per_pix);
+    const int c0 = (cj >> 2) * 32 + (cj & 3) * 4;
+    const float* xp = x + pix * C;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    if (c0 < C) a = *reinterpret_cast<const float4*>(xp + c0);
+    if (c0 + 16 < C) b = *reinterpret_cast<const float4*>(xp + c0 + 16);
+    half8 h;
+    h[0] = (_Float16)quantize_scaled<FMT, 4>(a.x, sd, sT); h[1] = (_Float16)quantize_scaled<FMT, 4>(a.y, sd, sT);
+    h[2] = (_Float16)quantize_scaled<FMT, 4>(a.z, sd, sT); h[3] = (_Float16)quantize_scaled<FMT, 4>(a.w, sd, sT);
+    h[4] = (_Float16)quantize_scaled<FMT, 4>(b.x, sd, sT); h[5] = (_Float16)quantize_scaled<FMT, 4>(b.y, sd, sT);
+    h[6] = (_Float16)quantize_scaled<FMT, 4>(b.z, sd, sT); h[7] = (_Float16)quantize_scaled<FMT, 4>(b.w, sd, sT);
+    if (c0 >= C) h = half8{0, 0, 0, 0, 0, 0, 0, 0};              // quantize(0) is +0 anyway; keep the pad exact
+    else if (c0 + 16 >= C) { h[4] = 0; h[5] = 0; h[6] = 0; h[7] = 0; }
+    *reinterpret_cast<half8*>(xe + idx * 8) = h;
+}
+
+// WM x WN = 8 waves; MT = output rows per wave.  Both operands arrive by LDS-DMA: no VALU work
+// in the main loop beyond addresses.
+template <int WM, int WN, int MT>
+__global__ __launch_bounds__(kDnThreads, (MT == 4 ? 2 : 4)) void k_dense_mfma(const DenseParams p) {
+    static_assert(WM * WN == 8, "8 waves");
+    constexpr int TH = WM * MT, BN = WN * 64, WT = BN * 128;  // WT: bytes of one tap's weight tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* wbuf = smem;            // [2][WT]
+    unsigned char* xsb = wbuf + 2 * WT;    // [2][x_pieces * 1 KiB]   (8 halo pixels x 128 B per piece)
+    const uint32_t xbytes = (uint32_t)p.x_pieces * 1024u;
 
     uint32_t b = xcd_remap(blockIdx.x, p.nblocks);   // channel slice slowest: an XCD's L2 holds one W slice
     const int tw = b % p.tiles_w; b /= p.tiles_w;
@@ -76,47 +109,34 @@ __global__ __launch_bounds__(kDnThreads) void k_dense_mfma(const DenseParams p) 
     const int n = b % p.N;
     const int nb = b / p.N;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 2, wn = wave & 3;          // 2 row-waves x 4 channel-waves
+    const int wm = wave / WN, wn = wave % WN;
     const int col = lane & 15, kq = lane >> 4;
     const int h_in0 = th * TH * p.S - p.ph, w_in0 = tw * kDnTW * p.S - p.pw;
 
-    // ---- halo staging: float4 item #i of a thread = (pixel (tid >> 4) + 32 i, channel quad kc)
-    const int kc = threadIdx.x & 15;
-    const uint32_t st_sub = (uint32_t)((kc & 7) >> 2) * 8u;
-    const int st_chunk = (kc >> 3) * 4 + (kc & 3);
-    const float* xn = p.x + (size_t)n * p.H * p.W * p.C;
-    auto halo_load = [&](int item, int chunk, float4& v, uint32_t& dst) {
-        const int pix = (threadIdx.x >> 4) + item * (kDnThreads / 16);
+    // ---- halo tile: piece q of a chunk = 8 consecutive halo pixels x 64 channels (fp16), one DMA.
+    // lane -> (pixel pc*8 + lane/8, LDS slot lane%8); the slot holds 16-byte chunk slot ^ swz(pixel).
+    const unsigned char* xen = reinterpret_cast<const unsigned char*>(p.xe) + (size_t)n * p.H * p.W * p.Cp * 2;
+    auto stage_x = [&](int pc, int chunk, int buf) {
+        const int pix = pc * 8 + (lane >> 3);
         const int ih = pix / p.IW, iw = pix - ih * p.IW;
         const int gh = h_in0 + ih, gw = w_in0 + iw;
-        const bool live = pix < p.n_pix;
-        const int k = chunk * 64 + kc * 4;
-        const bool inb = live && (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W && k < p.C;
-        // unconditional load (clamped address), zeroed where the conv pads / past C_in
-        v = *reinterpret_cast<const float4*>(xn + (inb ? (gh * p.W + gw) * p.C + k : 0));
-        if (!inb) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        dst = live ? dn_x_off(pix, st_chunk) + st_sub : 0xFFFFFFFFu;
-    };
-    auto halo_store = [&](const float4& v, uint32_t dst, unsigned char* xs) {
-        if (dst == 0xFFFFFFFFu) return;
-        half4 h;
-        h[0] = (_Float16)quantize_scaled<FMT, 4>(v.x, p.sd, sT);
-        h[1] = (_Float16)quantize_scaled<FMT, 4>(v.y, p.sd, sT);
-        h[2] = (_Float16)quantize_scaled<FMT, 4>(v.z, p.sd, sT);
-        h[3] = (_Float16)quantize_scaled<FMT, 4>(v.w, p.sd, sT);
-        *reinterpret_cast<half4*>(xs + dst) = h;
+        const int c16 = (lane & 7) ^ ((pix >> 1) & 7);            // source chunk for this slot (dn_x_off's swizzle)
+        const int kbyte = chunk * 128 + c16 * 16;
+        const bool inb = pix < p.n_pix && (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W && kbyte < p.Cp * 2;
+        const unsigned char* src = inb ? xen + ((size_t)(gh * p.W + gw) * p.Cp) * 2 + kbyte : p.zero_page + (lane & 7) * 16;
+        glds16(src, xsb + (size_t)buf * xbytes + (size_t)pc * 1024);
     };
 
-    // ---- weight tap tile: 32 pieces of 1 KiB (channel tile, k-step), 4 per wave, LDS-DMA
-    const int nt0 = nb * (kDnBN / 16);
+    // ---- weight tap tile: BN/8 pieces of 1 KiB (channel tile, k-step), WN per wave
+    const int nt0 = nb * (BN / 16);
     auto stage_w = [&](int tap, int chunk, int buf) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int pc = wave * 4 + j;                      // piece = (channel tile pc >> 1, k-step pc & 1)
+        for (int j = 0; j < WN; ++j) {
+            const int pc = wave * WN + j;                     // piece = (channel tile pc >> 1, k-step pc & 1)
             int nt = nt0 + (pc >> 1);
             nt = nt < p.n_tiles ? nt : p.n_tiles - 1;         // tiles past C_out: clamp (results never stored)
             const size_t o = (((size_t)tap * p.n_tiles + nt) * p.KS + (size_t)chunk * 2 + (pc & 1)) * 1024 + (size_t)lane * 16;
-            glds16(reinterpret_cast<const unsigned char*>(p.w) + o, wbuf + (size_t)buf * kDnWBytes + (size_t)pc * 1024);
+            glds16(reinterpret_cast<const unsigned char*>(p.w) + o, wbuf + (size_t)buf * WT + (size_t)pc * 1024);
         }
     };
 
@@ -128,36 +148,25 @@ __global__ __launch_bounds__(kDnThreads) void k_dense_mfma(const DenseParams p) 
 
     const int n_chunks = p.KS >> 1, n_taps = p.KH * p.KW;
     stage_w(0, 0, 0);
-    __syncthreads();  // LUT visible
-    for (int item = 0; item < p.x_items_per_thread; ++item) {  // chunk 0's halo (the only exposed HBM latency)
-        float4 v; uint32_t dst;
-        halo_load(item, 0, v, dst);
-        halo_store(v, dst, xsb);
-    }
+    for (int pc = wave; pc < p.x_pieces; pc += 8) stage_x(pc, 0, 0);
     __syncthreads();
 
     int wb = 0, xb = 0;
     for (int chunk = 0; chunk < n_chunks; ++chunk) {
         const bool more_chunks = chunk + 1 < n_chunks;
         const unsigned char* xs = xsb + (size_t)xb * xbytes;
-        unsigned char* xs_next = xsb + (size_t)(xb ^ 1) * xbytes;
         for (int tap = 0; tap < n_taps; ++tap) {
             const bool last_tap = tap + 1 == n_taps;
-            // next weight tile (next tap, or tap 0 of the next chunk): LDS-DMA into the other buffer
+            // next weight tile (next tap, or tap 0 of the next chunk) and a slice of the next chunk's halo
             if (!last_tap || more_chunks) stage_w(last_tap ? 0 : tap + 1, last_tap ? chunk + 1 : chunk, wb ^ 1);
-            // a slice of the next chunk's halo flies behind this tap's MFMAs
-            float4 xv[PER_TAP]; uint32_t xd[PER_TAP];
-#pragma unroll
-            for (int q = 0; q < PER_TAP; ++q) {
-                xd[q] = 0xFFFFFFFFu;
-                xv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-                const int item = tap * PER_TAP + q;
-                if (more_chunks && item < p.x_items_per_thread) halo_load(item, chunk + 1, xv[q], xd[q]);
+            if (more_chunks) {
+                for (int q = 0; q < p.x_per_tap; ++q) {
+                    const int pc = (tap * p.x_per_tap + q) * 8 + wave;
+                    if (pc < p.x_pieces) stage_x(pc, chunk + 1, xb ^ 1);
+                }
             }
-            __builtin_amdgcn_sched_barrier(0);  // keep the loads ahead of the MFMA block
-
             const int kh = tap / p.KW, kw = tap - kh * p.KW;
-            const unsigned char* wt = wbuf + (size_t)wb * kDnWBytes + (size_t)(wn * 4) * 2048 + lane * 16;
+            const unsigned char* wt = wbuf + (size_t)wb * WT + (size_t)(wn * 4) * 2048 + lane * 16;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 half8 wf[4];
@@ -171,10 +180,7 @@ __global__ __launch_bounds__(kDnThreads) void k_dense_mfma(const DenseParams p) 
                     for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf, acc[i][j], 0, 0, 0);
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int q = 0; q < PER_TAP; ++q) halo_store(xv[q], xd[q], xs_next);
-            __syncthreads();  // drains the LDS-DMA (vmcnt(0)); every wave is done with wbuf[wb] (and, on the last tap, xs)
+            __syncthreads();  // drains this tap's DMAs (vmcnt(0)); every wave is done with wbuf[wb]
             wb ^= 1;
         }
         xb ^= 1;
@@ -206,19 +212,46 @@ __global__ __launch_bounds__(kDnThreads) void k_dense_mfma(const DenseParams p) 
     }
 }
 
-// geometry helper shared with make_plan(): tile height and halo size for this descriptor
-static bool dense_geometry(const slfp_conv2d_desc& d, int* mt, int* ih, int* iw) {
-    const int S = d.stride_h;
-    for (int m : {4, 2}) {
-        const int th = 2 * m;
-        const int IH = (th - 1) * S + (int)d.kh, IW = (kDnTW - 1) * S + (int)d.kw;
-        const int items = (IH * IW * 16 + kDnThreads - 1) / kDnThreads;  // halo float4 per thread per chunk
-        if ((size_t)IH * IW * 128 <= 44 * 1024 && items <= 3 * (int)(d.kh * d.kw)) {
-            *mt = m; *ih = IH; *iw = IW;
-            return true;
-        }
+// ---- host side: pick the tiling ----------------------------------------------------------
+struct DenseCfg { int wm, wn, mt; };
+// instantiated tilings, widest first
+static const DenseCfg kDenseCfgs[] = {{2, 4, 4}, {4, 2, 4}, {4, 2, 2}, {4, 2, 1}, {8, 1, 2}, {8, 1, 1}};
+
+struct DenseGeom { DenseCfg cfg; int ih, iw, pieces, per_tap; size_t lds; int occ; };
+
+static bool dense_cfg_geometry(const slfp_conv2d_desc& d, const DenseCfg& c, DenseGeom* g) {
+    const int S = d.stride_h, th = c.wm * c.mt, taps = (int)(d.kh * d.kw);
+    g->cfg = c;
+    g->ih = (th - 1) * S + (int)d.kh;
+    g->iw = (kDnTW - 1) * S + (int)d.kw;
+    g->pieces = (g->ih * g->iw + 7) / 8;
+    g->per_tap = (int)ceil_div(ceil_div(g->pieces, 8), taps);
+    g->lds = 2 * (size_t)c.wn * 64 * 128 + 2 * (size_t)g->pieces * 1024;
+    // MT 4 tilings hold 64 accumulator VGPRs + fragments: compiled for one workgroup per CU; the others for two
+    g->occ = c.mt == 4 ? 1 : (g->lds <= 80 * 1024 ? 2 : 1);
+    return g->lds <= 160 * 1024;
+}
+
+// Relative cost of a tiling for this layer: workgroups per CU x padded tile MACs x a per-tiling
+// factor fitted to measured layer times (VGG-16 / ResNet-50 shapes, profiles/dense_cfg_sweep.sh):
+// small wave tiles re-read fragments and hit the barrier more often per MFMA, one-workgroup-per-CU
+// tilings have nobody to overlap their DMA waits with.
+static bool dense_choose(const slfp_conv2d_desc& d, int64_t h_out, int64_t w_out, DenseGeom* best) {
+    double best_cost = 0;
+    bool found = false;
+    for (const DenseCfg& c : kDenseCfgs) {
+        DenseGeom g;
+        if (!dense_cfg_geometry(d, c, &g)) continue;
+        const int th = c.wm * c.mt, bn = c.wn * 64;
+        const int64_t blocks = d.n * ceil_div(h_out, th) * ceil_div(w_out, kDnTW) * ceil_div(d.c_out, bn);
+        const int64_t per_cu = ceil_div(blocks, 256);
+        double f = c.mt == 4 ? (c.wn == 4 ? 1.12 : 1.15) : (c.mt == 2 && c.wn == 2 ? 1.0 : 1.5);
+        if (c.mt != 4 && g.occ < 2) f *= 1.15;   // built for two workgroups per CU but LDS only fits one
+        if (per_cu < g.occ) f *= 1.3;            // too few workgroups to pair up
+        const double cost = (double)per_cu * th * bn * f;
+        if (!found || cost < best_cost) { best_cost = cost; *best = g; found = true; }
     }
-    return false;
+    return found;
 }
 
 bool dense_mfma_applicable(const slfp_conv2d_desc& d, int passes) {
@@ -226,15 +259,23 @@ bool dense_mfma_applicable(const slfp_conv2d_desc& d, int passes) {
     if (d.stride_h != d.stride_w || d.stride_h > 2) return false;
     if (d.c_in % 4 || d.c_in < 16 || d.c_out % 4) return false;
     if (d.qbits == 8 && passes == 3) return false;  // the float32-equivalent mode stays on k_direct
-    if ((int64_t)d.h * d.w * d.c_in >= (1ll << 30)) return false;
-    int mt, ih, iw;
-    return dense_geometry(d, &mt, &ih, &iw);
+    if ((int64_t)d.h * d.w * (d.c_in + 31) >= (1ll << 30)) return false;
+    DenseGeom g;
+    for (const DenseCfg& c : kDenseCfgs)
+        if (dense_cfg_geometry(d, c, &g)) return true;
+    return false;
 }
 
-template <int FMT, int MT, int PER_TAP>
-static int launch_dense_t(DenseParams& p, hipStream_t stream) {
-    const size_t lds = 64 + 2 * (size_t)kDnWBytes + 2 * (size_t)p.n_pix * 128;
-    auto fn = k_dense_mfma<FMT, MT, PER_TAP>;
+static int64_t dense_cp(const slfp_conv2d_desc& d) { return ceil_div(d.c_in, 32) * 32; }
+
+// workspace = [256 B zero page][pre-encoded input: N*H*W*Cp fp16]
+size_t dense_mfma_workspace_bytes(const slfp_conv2d_desc& d) {
+    return 256 + (((size_t)d.n * d.h * d.w * dense_cp(d) * sizeof(_Float16)) + 255 & ~(size_t)255);
+}
+
+template <int WM, int WN, int MT>
+static int launch_dense_t(DenseParams& p, size_t lds, hipStream_t stream) {
+    auto fn = k_dense_mfma<WM, WN, MT>;
     static bool lds_raised = false;  // > 64 KiB of dynamic LDS needs the opt-in once per kernel
     if (!lds_raised) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -246,30 +287,46 @@ static int launch_dense_t(DenseParams& p, hipStream_t stream) {
 }
 
 int launch_dense_mfma(const slfp_conv2d_desc& d, const ConvPlan& plan, const float* x, const void* wblob,
-                      const float* bias, const PostOp& post, float* y, hipStream_t stream) {
+                      const float* bias, const PostOp& post, float* y, void* workspace, hipStream_t stream) {
+    DenseGeom g;
+    if (!dense_choose(d, plan.h_out, plan.w_out, &g)) return fail(SLFP_ERR_UNSUPPORTED, "dense MFMA conv: no tiling fits");
+    if (!workspace) return fail(SLFP_ERR_BAD_ARG, "dense MFMA conv: workspace required (slfp_conv2d_workspace_bytes)");
+    // ---- pass 1: encode the input once (every element is reused KH*KW * C_out times by pass 2)
+    unsigned char* zero_page = reinterpret_cast<unsigned char*>(workspace);
+    _Float16* xe = reinterpret_cast<_Float16*>(zero_page + 256);
+    const int cp = (int)dense_cp(d);
+    const int64_t n_chunks16 = d.n * d.h * d.w * (cp / 8);
+    const ScaleDiv sd = make_scale_div(d.ka, 4);
+    const unsigned egrid = (unsigned)ceil_div(n_chunks16, 256);
+    if (plan.fmt_act == kFmtAct8)
+        hipLaunchKernelGGL((k_dense_encode<kFmtAct8>), dim3(egrid), dim3(256), 0, stream, x, xe, zero_page, n_chunks16, (int)d.c_in, cp, sd);
+    else
+        hipLaunchKernelGGL((k_dense_encode<kFmtSfp7>), dim3(egrid), dim3(256), 0, stream, x, xe, zero_page, n_chunks16, (int)d.c_in, cp, sd);
+    int rc = check_launch("slfp dense encode kernel");
+    if (rc != SLFP_OK) return rc;
+    // ---- pass 2: implicit GEMM
     DenseParams p;
-    int mt;
-    if (!dense_geometry(d, &mt, &p.IH, &p.IW)) return fail(SLFP_ERR_UNSUPPORTED, "dense MFMA conv: halo tile too large");
-    p.x = x; p.w = reinterpret_cast<const _Float16*>(wblob); p.bias = bias; p.y = y; p.post = post;
-    p.N = (int)d.n; p.H = (int)d.h; p.W = (int)d.w; p.C = (int)d.c_in; p.O = (int)d.c_out;
+    p.xe = xe; p.zero_page = zero_page;
+    p.w = reinterpret_cast<const _Float16*>(wblob); p.bias = bias; p.y = y; p.post = post;
+    p.N = (int)d.n; p.H = (int)d.h; p.W = (int)d.w; p.Cp = cp; p.O = (int)d.c_out;
     p.KH = (int)d.kh; p.KW = (int)d.kw; p.S = d.stride_h; p.ph = d.pad_h; p.pw = d.pad_w;
     p.Ho = (int)plan.h_out; p.Wo = (int)plan.w_out;
-    p.tiles_h = (int)ceil_div(p.Ho, 2 * mt); p.tiles_w = (int)ceil_div(p.Wo, kDnTW);
-    p.n_blocks = (int)ceil_div((int64_t)p.O, kDnBN);
-    p.n_pix = p.IH * p.IW;
+    p.IH = g.ih; p.IW = g.iw; p.n_pix = g.ih * g.iw; p.x_pieces = g.pieces; p.x_per_tap = g.per_tap;
+    p.tiles_h = (int)ceil_div(p.Ho, g.cfg.wm * g.cfg.mt); p.tiles_w = (int)ceil_div(p.Wo, kDnTW);
+    p.n_blocks = (int)ceil_div((int64_t)p.O, g.cfg.wn * 64);
     p.KS = (int)(plan.k_pad / 32); p.n_tiles = (int)(plan.n_pad / 16);
-    p.x_items_per_thread = (int)ceil_div((int64_t)p.n_pix * 16, kDnThreads);
-    p.sd = make_scale_div(d.ka, 4);
     p.s1 = plan.s1; p.s2 = plan.s2; p.s1x = plan.s1 * (1.0f / 256.0f);
     const int64_t nblocks = (int64_t)p.N * p.tiles_h * p.tiles_w * p.n_blocks;
     if (nblocks > 0x7FFFFFFF) return fail(SLFP_ERR_UNSUPPORTED, "dense MFMA conv: grid too large");
     p.nblocks = (uint32_t)nblocks;
-    const int per_tap = (int)ceil_div(p.x_items_per_thread, (int64_t)p.KH * p.KW);  // 1..3, see dense_geometry()
-    const bool a8 = plan.fmt_act == kFmtAct8;
-#define SLFP_DN(MTT, PT) (a8 ? launch_dense_t<kFmtAct8, MTT, PT>(p, stream) : launch_dense_t<kFmtSfp7, MTT, PT>(p, stream))
-    if (mt == 4) return per_tap == 1 ? SLFP_DN(4, 1) : (per_tap == 2 ? SLFP_DN(4, 2) : SLFP_DN(4, 3));
-    return per_tap == 1 ? SLFP_DN(2, 1) : (per_tap == 2 ? SLFP_DN(2, 2) : SLFP_DN(2, 3));
-#undef SLFP_DN
+    switch (g.cfg.wm * 100 + g.cfg.wn * 10 + g.cfg.mt) {
+        case 244: return launch_dense_t<2, 4, 4>(p, g.lds, stream);
+        case 424: return launch_dense_t<4, 2, 4>(p, g.lds, stream);
+        case 422: return launch_dense_t<4, 2, 2>(p, g.lds, stream);
+        case 421: return launch_dense_t<4, 2, 1>(p, g.lds, stream);
+        case 812: return launch_dense_t<8, 1, 2>(p, g.lds, stream);
+        default: return launch_dense_t<8, 1, 1>(p, g.lds, stream);
+    }
 }
 
 }  // namespace slfp

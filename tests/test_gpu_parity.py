@@ -244,8 +244,11 @@ def _raw_conv(lib, dev, x_nhwc, w_oihw, bias, stride, pad, groups, Ka, Kw, qbits
     blob = torch.empty(L.slfp_conv2d_wprep_bytes(ctypes.byref(d)), dtype=torch.uint8, device=dev)
     lib.check(L.slfp_conv2d_prepare_weights(ctypes.byref(d), w_oihw.data_ptr(), blob.data_ptr(), None, _stream()))
     y = torch.empty((N, ho.value, wo.value, O), dtype=torch.float32, device=dev)
+    ws_bytes = L.slfp_conv2d_workspace_bytes(ctypes.byref(d))  # dense k x k: the input encoded once to fp16
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
     lib.check(L.slfp_conv2d_fwd(ctypes.byref(d), x_nhwc.data_ptr(), blob.data_ptr(),
-                                bias.data_ptr() if bias is not None else None, y.data_ptr(), None, None, _stream()))
+                                bias.data_ptr() if bias is not None else None, y.data_ptr(), None,
+                                ws.data_ptr() if ws is not None else None, _stream()))
     return y, L.slfp_conv2d_kernel_name(ctypes.byref(d)).decode()
 
 
