@@ -53,6 +53,13 @@ int make_plan(const slfp_conv2d_desc* d, ConvPlan* plan) {
         plan->k_pad = ceil_div(d->c_in, 64) * 64;
         plan->n_pad = ceil_div(d->c_out, 64) * 64;
         plan->wprep_bytes = round256((size_t)2 * plan->k_pad * plan->n_pad * sizeof(_Float16));
+    } else if (stem_mfma_applicable(*d, plan->passes)) {
+        plan->family = kStemMfma;
+        int ksub, nt;
+        stem_mfma_blob_shape(*d, &ksub, &nt);
+        plan->k_pad = ksub;  // k-steps per tap row
+        plan->n_pad = nt;    // 16-channel tiles
+        plan->wprep_bytes = round256((size_t)d->kh * ksub * nt * 1024);
     } else if (dense_mfma_applicable(*d, plan->passes)) {
         plan->family = kDenseMfma;
         plan->k_pad = ceil_div(d->c_in, 64) * 64;
@@ -87,6 +94,12 @@ __global__ __launch_bounds__(256) void k_prepare(const float* __restrict__ w, vo
         reinterpret_cast<float*>(prep)[(size_t)(kh * 3 + kw) * O + o] = q;  // [9][C]
     } else if (family == kDirect) {
         reinterpret_cast<float*>(prep)[((size_t)(kh * KW + kw) * Cg + ci) * O + o] = q;  // [KH][KW][Cg][O]
+    } else if (family == kStemMfma) {
+        // K = (kh, run element r = kw*C_in + ci padded to 32*KS): k-step kh*KS + r/32, lane-quarter (r%32)/8;
+        // `plane` carries the number of channel tiles: conv_stem_mfma.hip
+        const int r = kw * Cg + ci, ks = kh * KS + (r >> 5);
+        const size_t at = ((((size_t)ks * plane + (o >> 4)) * 64) + (size_t)(((r & 31) >> 3) * 16 + (o & 15))) * 8 + (r & 7);
+        reinterpret_cast<_Float16*>(prep)[at] = (_Float16)(16.0f * q);
     } else if (family == kDenseMfma) {
         // tap-major copy of the pointwise fragment order (single fp16 plane): conv_dense.hip
         const int nt = o >> 4, row = o & 15, ks = ci >> 5, kk = ci & 31;
@@ -112,11 +125,11 @@ int launch_prepare_weights(const slfp_conv2d_desc& d, const ConvPlan& p, const f
                            float* weight_q_oihw, hipStream_t stream) {
     const int Cg = (int)(d.c_in / d.groups);
     const int64_t total = d.c_out * Cg * d.kh * d.kw;
-    if (p.family == kPointwise || p.family == kDenseMfma) {
+    if (p.family == kPointwise || p.family == kDenseMfma || p.family == kStemMfma) {
         if (hipMemsetAsync(wprep, 0, p.wprep_bytes, stream) != hipSuccess) return check_launch("hipMemsetAsync(wprep)");
     }
-    const int64_t plane = p.k_pad * p.n_pad;
-    const int KS = (int)(p.k_pad / 32);
+    const int64_t plane = p.family == kStemMfma ? p.n_pad : p.k_pad * p.n_pad;
+    const int KS = p.family == kStemMfma ? (int)p.k_pad : (int)(p.k_pad / 32);
     const unsigned grid = (unsigned)ceil_div(total, 256);
     const ScaleDiv sd = make_scale_div(d.kw_scale);
     if (p.fmt_w == kFmtW8)
@@ -134,6 +147,7 @@ static const char* family_name(const ConvPlan& p, const slfp_conv2d_desc& d) {
         case kDw3x3: return "dw3x3_nhwc";
         case kPointwise: return p.fmt_act == kFmtSfp7 ? "pw_mfma_f16_exact" : (p.passes == 3 ? "pw_mfma_f16x3" : "pw_mfma_f16x1");
         case kDenseMfma: return p.fmt_act == kFmtSfp7 ? "dense_mfma_f16_exact" : "dense_mfma_f16x1";
+        case kStemMfma: return p.fmt_act == kFmtSfp7 ? "stem_mfma_f16_exact" : "stem_mfma_f16x1";
         default: return "direct_nhwc";
     }
 }
@@ -182,6 +196,7 @@ size_t slfp_conv2d_workspace_bytes(const slfp_conv2d_desc* d) {
     if (d->x_layout == SLFP_LAYOUT_NCHW) b += round256((size_t)d->n * d->c_in * d->h * d->w * sizeof(float));
     if (d->y_layout == SLFP_LAYOUT_NCHW) b += round256((size_t)d->n * d->c_out * p.h_out * p.w_out * sizeof(float));
     if (p.family == kDenseMfma) b += dense_mfma_workspace_bytes(*d);  // the input encoded once to fp16
+    if (p.family == kStemMfma) b += stem_mfma_workspace_bytes(*d, p.w_out);
     return b;
 }
 
@@ -230,6 +245,7 @@ int slfp_conv2d_fwd_post(const slfp_conv2d_desc* d, const float* x, const void* 
         case kDw3x3: rc = launch_dw3x3(*d, p, x_nhwc, reinterpret_cast<const float*>(wprep), bias, post, y_nhwc, st); break;
         case kPointwise: rc = launch_pointwise(*d, p, x_nhwc, wprep, bias, post, y_nhwc, st); break;
         case kDenseMfma: rc = launch_dense_mfma(*d, p, x_nhwc, wprep, bias, post, y_nhwc, ws, st); break;
+        case kStemMfma: rc = launch_stem_mfma(*d, p, x_nhwc, wprep, bias, post, y_nhwc, ws, st); break;
         default: rc = launch_direct(*d, p, x_nhwc, reinterpret_cast<const float*>(wprep), bias, post, y_nhwc, st); break;
     }
     if (rc != SLFP_OK) return rc;

@@ -2,22 +2,26 @@
 // matrix cores (VGG-16's 3x3 layers, ResNet-50's 3x3 layers, SqueezeNet's expand3x3, AlexNet 5x5).
 //
 // Replaces Conv2d_Q.forward (utils/conv2d_func.py:20-25 / :41-47) for groups == 1, KH*KW > 1.
-// These layers are compute-bound (VGG-16: 337 flop/B), so the contraction must run on MFMA; the
-// structure is the pointwise GEMM of conv_pw.hip with the K dimension = (tap, input channel):
-//   * workgroup = TH x 16 output pixels x BN output channels, 8 waves as WM (rows) x WN (channels),
-//     BN = 64 WN, TH = WM * MT; accumulators MT x 4 tiles of 16x16 per wave;
-//   * per 64-channel chunk the (TH-1)*S+KH x 15*S+KW input HALO tile is read once from HBM,
-//     x/Ka + SLFP encode applied inline, and stored as fp16 in a swizzled LDS tile: every one of
-//     the KH*KW taps then reads its shifted 16-pixel fragments from the same tile (the encode is
-//     amortised over KH*KW * BN MACs per element).  The NEXT chunk's halo is fetched in slices
-//     behind the taps' MFMAs, encoded as it lands and parked in registers (2 VGPRs per float4),
-//     then written over the single LDS tile between two barriers at the chunk boundary;
-//   * per tap the BN x 64 fp16 weight tile (fragment-ordered blob, tap-major) is brought in by
-//     LDS-DMA (global_load_lds, no VGPR staging) into a double buffer, one barrier per tap;
-//   * LDS footprint <= 80 KiB so that two workgroups share a CU: one's barrier / DMA wait is the
-//     other's MFMA time;
-//   * fp16 operands (both pre-scaled by 2^4, see conv_pw.hip), float32 accumulation, the
-//     reference's (out*Ka)*Kw roundings and the optional fused BN/ReLU post-op in the epilogue.
+// These layers are compute-bound (VGG-16: 337 flop/B), so the contraction runs on MFMA, in two passes:
+//   1. k_dense_encode: x/Ka + SLFP encode applied ONCE per input element (fused into the GEMM it
+//      would be redone for every overlapping halo and every output-channel slice: 3-5x, and the
+//      encode's ~22 VALU ops per element then rival the MFMA time); the result, fp16(16 * QA(x/Ka)),
+//      goes to the caller's workspace in B-fragment chunk order (6 B of HBM traffic per element
+//      on layers that do >= 500 flop per element);
+//   2. k_dense_mfma: the pointwise GEMM of conv_pw.hip with K = (tap, input channel):
+//      * workgroup = TH x 16 output pixels x BN output channels, 8 waves as WM (rows) x WN
+//        (channels), BN = 64 WN, TH = WM * MT; accumulators MT x 4 tiles of 16x16 per wave;
+//      * per 64-channel chunk the (TH-1)*S+KH x 15*S+KW input HALO tile sits in a swizzled LDS
+//        tile and every one of the KH*KW taps reads its shifted 16-pixel fragments from it; the
+//        NEXT chunk's halo arrives in 1 KiB LDS-DMA pieces (global_load_lds, 8 pixels each, the
+//        swizzle applied on the source address, conv padding served from a zero page) behind
+//        the taps' MFMAs, into the second buffer;
+//      * per tap the BN x 64 fp16 weight tile (fragment-ordered blob, tap-major) is brought in
+//        by LDS-DMA into a double buffer; one barrier per tap; no VALU work beyond addresses;
+//      * tilings with <= 80 KiB of LDS run two workgroups per CU (one's barrier / DMA wait is
+//        the other's MFMA time); dense_choose() picks the tiling per layer;
+//      * fp16 operands (both pre-scaled by 2^4, see conv_pw.hip), float32 accumulation, the
+//        reference's (out*Ka)*Kw roundings and the optional fused BN/ReLU post-op in the epilogue.
 // Single-pass fp16 (SLFP<3,4>: ~2.5e-4 tensor-relative, the north-star 1e-3 bar) or exact
 // (SFP<3,3>).  The float32-equivalent mode of these layers stays on k_direct.
 #include "slfp_device.hpp"

@@ -1,0 +1,214 @@
+// conv_stem_mfma.hip -- large-kernel image stems on the matrix cores: ResNet-50 7x7 s2 3->64
+// (nets_imgnet/resnet.py), SqueezeNet 7x7 s2 3->96 (+bias), AlexNet 11x11 s4 3->64 (+bias).
+//
+// Replaces Conv2d_Q.forward (utils/conv2d_func.py:20-25 / :41-47) for groups == 1, C_in <= 4,
+// KH*KW >= 25.  At 147-363 MACs per output value these layers are compute-bound on the fp32
+// VALU path (k_stem / k_direct reach ~30 TFLOP/s), yet their HBM floor is the output write alone.
+// With NHWC and C_in = 3 the KW*C_in input values one tap ROW contributes to an output pixel are
+// CONTIGUOUS in memory, so the contraction is arranged as K = KH x (row run padded to Rp = 32 or 64):
+//   1. k_stem_im2row: for every input row ih and output column ow, the run
+//      x[n][ih][ow*S-pw .. +KW-1][0..C) is encoded (x/Ka, SLFP) once to fp16 (x16) and written,
+//      zero-padded to Rp, to the workspace: xe[n][ih][ow][Rp].  16 consecutive output pixels of
+//      a row are then 16*Rp contiguous halfs = exactly the B fragments of Rp/32 k-steps;
+//   2. k_stem_mfma: all of W (fragment-ordered [kh*Rp/32 + sub][channel tile], 28-88 KiB) stays in
+//      LDS; a wave owns 16 output pixels x all output channels, loads its B fragments straight
+//      from xe (1 KiB contiguous per k-step, L2/MALL hits: each run is reused by KH/S output rows),
+//      16x16x32 fp16 MFMA, float32 accumulation, the reference's (out*Ka)*Kw roundings, bias and
+//      the optional fused BN/ReLU post-op in the epilogue.  Tap rows that fall in the vertical
+//      padding are skipped (wave-uniform).
+// Precision: single-pass fp16 (SLFP<3,4>) / exact (SFP<3,3>), as conv_dense.hip.
+#include "slfp_device.hpp"
+#include "slfp_host.hpp"
+
+namespace slfp {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+constexpr int kSmThreads = 512;
+
+struct StemMfmaParams {
+    const _Float16* xe;  // [N][H][Wo][Rp]
+    const _Float16* w;   // [KS][NT][64 lanes][8]
+    const float* bias;
+    float* y;
+    int N, H, O, KH, S, ph, Ho, Wo;
+    int rp_shift;        // Rp = 32 << rp_shift... (5 or 6: log2 Rp)
+    int KS;              // KH * Rp/32
+    int segs;            // ceil(Wo / 16)
+    int64_t units;       // N * Ho * segs
+    float s1, s2, s1x;
+    PostOp post;
+};
+
+template <int FMT>
+__global__ __launch_bounds__(256) void k_stem_im2row(const float* __restrict__ x, _Float16* __restrict__ xe,
+                                                     int64_t n_chunks16, int H, int W, int C, int Wo, int S, int pw,
+                                                     int RL, int rp_shift, const ScaleDiv sd) {
+    __shared__ uint32_t sT[16];
+    lut_fill<FMT>(sT);
+    __syncthreads();
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_chunks16) return;
+    const int cps = rp_shift - 3;                       // log2(16-byte chunks per run)
+    const int cj = (int)(idx & ((1 << cps) - 1));
+    const int64_t run = idx >> cps;                     // (n*H + ih)*Wo + ow
+    const int ow = (int)(run % Wo);
+    const int64_t row = run / Wo;                       // n*H + ih
+    const float* xr = x + row * (int64_t)W * C;
+    const int e0 = (ow * S - pw) * C + cj * 8;          // element offset inside the input row
+    half8 h;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int r = cj * 8 + j, e = e0 + j;
+        float v = 0.f;
+        if (r < RL && e >= 0 && e < W * C) v = quantize_scaled<FMT, 4>(xr[e], sd, sT);
+        h[j] = (_Float16)v;
+    }
+    *reinterpret_cast<half8*>(xe + idx * 8) = h;
+}
+
+// NT = 16-channel tiles (4: C_out <= 64, 6: C_out <= 96).  KB = k-steps whose B fragments are in flight.
+template <int NT, int KB>
+__global__ __launch_bounds__(kSmThreads, 2) void k_stem_mfma(const StemMfmaParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // W: [KS][NT][1 KiB]
+    {
+        const int n16 = p.KS * NT * 64;
+        const uint4* src = reinterpret_cast<const uint4*>(p.w);
+        uint4* dst = reinterpret_cast<uint4*>(smem);
+        for (int i = threadIdx.x; i < n16; i += kSmThreads) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 15, kq = lane >> 4;
+    const int ksub = 1 << (p.rp_shift - 5);
+    const int64_t stride = (int64_t)gridDim.x * (kSmThreads / 64);
+    for (int64_t u = (int64_t)blockIdx.x * (kSmThreads / 64) + wave; u < p.units; u += stride) {
+        const int seg = (int)(u % p.segs);
+        const int64_t t = u / p.segs;
+        const int oh = (int)(t % p.Ho);
+        const int n = (int)(t / p.Ho);
+        const int ow = seg * 16 + col;
+        const int owc = ow < p.Wo ? ow : p.Wo - 1;      // clamp the loads of a ragged last segment
+        const int ih0 = oh * p.S - p.ph;
+        const _Float16* xl = p.xe + ((((int64_t)n * p.H) * p.Wo + owc) << p.rp_shift) + kq * 8;
+        floatx4 acc[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+        for (int ks0 = 0; ks0 < p.KS; ks0 += KB) {
+            half8 xf[KB];
+#pragma unroll
+            for (int q = 0; q < KB; ++q) {
+                const int ks = ks0 + q;
+                const int kh = ks >> (p.rp_shift - 5), sub = ks & (ksub - 1);
+                const int ih = ih0 + kh;
+                xf[q] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+                if (ks < p.KS && (unsigned)ih < (unsigned)p.H)   // wave-uniform
+                    xf[q] = *reinterpret_cast<const half8*>(xl + (((int64_t)ih * p.Wo) << p.rp_shift) + sub * 32);
+            }
+#pragma unroll
+            for (int q = 0; q < KB; ++q) {
+                const int ks = ks0 + q;
+                if (ks >= p.KS || (unsigned)(ih0 + (ks >> (p.rp_shift - 5))) >= (unsigned)p.H) continue;
+                const unsigned char* wt = smem + ((size_t)ks * NT) * 1024 + lane * 16;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const half8 wf = *reinterpret_cast<const half8*>(wt + j * 1024);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[q], acc[j], 0, 0, 0);
+                }
+            }
+        }
+        if (ow < p.Wo) {
+            float* yp = p.y + (((int64_t)n * p.Ho + oh) * p.Wo + ow) * p.O;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int ch = j * 16 + kq * 4;
+                if (ch >= p.O) continue;
+                float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.bias) {
+                    const float4 bb = *reinterpret_cast<const float4*>(p.bias + ch);
+                    bq = make_float4(256.f * ((bb.x / p.s1) / p.s2), 256.f * ((bb.y / p.s1) / p.s2),
+                                     256.f * ((bb.z / p.s1) / p.s2), 256.f * ((bb.w / p.s1) / p.s2));
+                }
+                float4 r;
+                r.x = ((acc[j][0] + bq.x) * p.s1x) * p.s2;
+                r.y = ((acc[j][1] + bq.y) * p.s1x) * p.s2;
+                r.z = ((acc[j][2] + bq.z) * p.s1x) * p.s2;
+                r.w = ((acc[j][3] + bq.w) * p.s1x) * p.s2;
+                *reinterpret_cast<float4*>(yp + ch) = post_apply(r, p.post, ch);
+            }
+        }
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------
+static int stem_rp(const slfp_conv2d_desc& d) { return (int)ceil_div(d.kw * d.c_in, 32) * 32; }
+
+bool stem_mfma_applicable(const slfp_conv2d_desc& d, int passes) {
+    if (d.groups != 1 || d.c_in > 4 || d.dil_h != 1 || d.dil_w != 1 || d.stride_h != d.stride_w) return false;
+    if (d.kh * d.kw < 25) return false;                  // 3x3 / 5x5-ish stems: k_stem is at the HBM floor already
+    if (d.c_out % 4 || d.c_out > 96) return false;
+    if (d.qbits == 8 && passes == 3) return false;      // the float32-equivalent mode stays on k_stem / k_direct
+    const int rp = stem_rp(d);
+    if (rp > 64) return false;
+    const int nt = d.c_out <= 64 ? 4 : 6;
+    return (size_t)d.kh * (rp / 32) * nt * 1024 <= 150 * 1024;
+}
+
+void stem_mfma_blob_shape(const slfp_conv2d_desc& d, int* ksub, int* nt) {
+    *ksub = stem_rp(d) / 32;
+    *nt = d.c_out <= 64 ? 4 : 6;
+}
+
+// workspace = the im2row'ed, encoded input: N*H*Wo*Rp fp16
+size_t stem_mfma_workspace_bytes(const slfp_conv2d_desc& d, int64_t w_out) {
+    return (((size_t)d.n * d.h * w_out * stem_rp(d) * sizeof(_Float16)) + 255) & ~(size_t)255;
+}
+
+template <int NT>
+static int launch_stem_mfma_t(const StemMfmaParams& p, size_t lds, unsigned grid, hipStream_t stream) {
+    auto fn = k_stem_mfma<NT, 8>;
+    static bool lds_raised = false;
+    if (!lds_raised) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return check_launch("hipFuncSetAttribute(stem_mfma)");
+        lds_raised = true;
+    }
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(kSmThreads), lds, stream, p);
+    return check_launch("slfp MFMA stem kernel");
+}
+
+int launch_stem_mfma(const slfp_conv2d_desc& d, const ConvPlan& plan, const float* x, const void* wblob,
+                     const float* bias, const PostOp& post, float* y, void* workspace, hipStream_t stream) {
+    if (!workspace) return fail(SLFP_ERR_BAD_ARG, "MFMA stem: workspace required (slfp_conv2d_workspace_bytes)");
+    const int rp = stem_rp(d), rp_shift = rp == 32 ? 5 : 6;
+    int ksub, nt;
+    stem_mfma_blob_shape(d, &ksub, &nt);
+    _Float16* xe = reinterpret_cast<_Float16*>(workspace);
+    const int64_t n_chunks16 = d.n * d.h * plan.w_out * (rp / 8);
+    const ScaleDiv sd = make_scale_div(d.ka, 4);
+    const unsigned egrid = (unsigned)ceil_div(n_chunks16, 256);
+    const int RL = (int)(d.kw * d.c_in);
+    if (plan.fmt_act == kFmtAct8)
+        hipLaunchKernelGGL((k_stem_im2row<kFmtAct8>), dim3(egrid), dim3(256), 0, stream, x, xe, n_chunks16, (int)d.h, (int)d.w,
+                           (int)d.c_in, (int)plan.w_out, d.stride_w, d.pad_w, RL, rp_shift, sd);
+    else
+        hipLaunchKernelGGL((k_stem_im2row<kFmtSfp7>), dim3(egrid), dim3(256), 0, stream, x, xe, n_chunks16, (int)d.h, (int)d.w,
+                           (int)d.c_in, (int)plan.w_out, d.stride_w, d.pad_w, RL, rp_shift, sd);
+    int rc = check_launch("slfp stem im2row kernel");
+    if (rc != SLFP_OK) return rc;
+    StemMfmaParams p;
+    p.xe = xe; p.w = reinterpret_cast<const _Float16*>(wblob); p.bias = bias; p.y = y; p.post = post;
+    p.N = (int)d.n; p.H = (int)d.h; p.O = (int)d.c_out; p.KH = (int)d.kh; p.S = d.stride_h; p.ph = d.pad_h;
+    p.Ho = (int)plan.h_out; p.Wo = (int)plan.w_out;
+    p.rp_shift = rp_shift; p.KS = (int)d.kh * ksub;
+    p.segs = (int)ceil_div(p.Wo, 16);
+    p.units = (int64_t)p.N * p.Ho * p.segs;
+    p.s1 = plan.s1; p.s2 = plan.s2; p.s1x = plan.s1 * (1.0f / 256.0f);
+    const size_t lds = (size_t)p.KS * nt * 1024;
+    const int occ = (int)std::max<size_t>(1, std::min<size_t>(2, (160 * 1024) / lds));
+    const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(p.units, kSmThreads / 64), 256 * occ);
+    return nt == 4 ? launch_stem_mfma_t<4>(p, lds, grid, stream) : launch_stem_mfma_t<6>(p, lds, grid, stream);
+}
+
+}  // namespace slfp

@@ -33,7 +33,7 @@ inline ScaleDiv make_scale_div(float d, int esh = 0) {
 }
 
 // Kernel families (slfp_conv2d_kernel_name reports them).
-enum KernelFamily { kDw3x3 = 0, kPointwise = 1, kDirect = 2, kDenseMfma = 3 };
+enum KernelFamily { kDw3x3 = 0, kPointwise = 1, kDirect = 2, kDenseMfma = 3, kStemMfma = 4 };
 
 struct ConvPlan {
     KernelFamily family;
@@ -67,6 +67,14 @@ int launch_dense_mfma(const slfp_conv2d_desc& d, const ConvPlan& p, const float*
                       const float* bias, const PostOp& post, float* y, void* workspace, hipStream_t stream);
 int launch_prepare_weights(const slfp_conv2d_desc& d, const ConvPlan& p, const float* w_oihw, void* wprep,
                            float* weight_q_oihw, hipStream_t stream);
+
+// large-kernel image stems on MFMA (conv_stem_mfma.hip); wblob = [kh*ksub + sub][nt][64][8] fp16;
+// `workspace` receives the im2row'ed, encoded input
+bool stem_mfma_applicable(const slfp_conv2d_desc& d, int passes);
+void stem_mfma_blob_shape(const slfp_conv2d_desc& d, int* ksub, int* nt);
+size_t stem_mfma_workspace_bytes(const slfp_conv2d_desc& d, int64_t w_out);
+int launch_stem_mfma(const slfp_conv2d_desc& d, const ConvPlan& p, const float* x, const void* wblob,
+                     const float* bias, const PostOp& post, float* y, void* workspace, hipStream_t stream);
 
 // XCD-aware block remap (MI355X: 8 XCDs, blocks are dealt round-robin over them, so
 // blocks b and b+8 share an L2).  Maps the hardware block id to a logical id such that

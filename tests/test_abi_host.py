@@ -55,6 +55,12 @@ def test_kernel_selection_and_sizes():
     dense.qbits = 7
     assert name(dense) == "dense_mfma_f16_exact"
     assert name(_desc(c_in=8, c_out=32, groups=1)) == "direct_nhwc"               # too few channels for a k-step
+    big_stem = _desc(c_in=3, c_out=64, groups=1, kh=7, kw=7, stride_h=2, stride_w=2, pad_h=3, pad_w=3, h=64, w=64)
+    assert name(big_stem) == "stem_mfma_f16x1"                                   # 7x7 image stem: im2row + MFMA
+    assert L.slfp_conv2d_wprep_bytes(ctypes.byref(big_stem)) == 7 * 1 * 4 * 1024  # [kh][32-k step][4 channel tiles][1 KiB]
+    assert L.slfp_conv2d_workspace_bytes(ctypes.byref(big_stem)) == 2 * 64 * 32 * 32 * 2  # N*H*Wo*Rp fp16
+    big_stem.mfma_passes = _lib.MFMA_F16X3
+    assert name(big_stem) == "stem_nhwc"
     assert name(_desc(c_in=16, c_out=32, groups=1, dil_h=2, dil_w=2)) == "direct_nhwc"
     ho, wo = ctypes.c_int64(), ctypes.c_int64()
     assert L.slfp_conv2d_out_shape(ctypes.byref(_desc(h=224, w=224, c_in=3, c_out=32, groups=1, stride_h=2, stride_w=2)),

@@ -191,6 +191,7 @@ def test_conv_golden_cases(lib, dev, conv_golden, layout, passes):
         assert {"dw3x3_nhwc", "direct_nhwc", "stem_nhwc", "pw_mfma_f16_exact", "passthrough"} <= seen, seen
         assert ("pw_mfma_f16x3" if passes == 3 else "pw_mfma_f16x1") in seen, seen
         assert "dense_mfma_f16_exact" in seen and (passes == 3 or "dense_mfma_f16x1" in seen), seen
+        assert "stem_mfma_f16_exact" in seen and (passes == 3 or "stem_mfma_f16x1" in seen), seen
     finally:
         cf.options.mfma_passes = 0
 
@@ -324,6 +325,21 @@ def test_dense_kxk_mfma_vs_oracle(lib, dev):
         # the float32-equivalent mode of these layers stays on the fp32 kernel
         kern, _, _ = _check_against_oracle(lib, dev, 1, C, H, O, k, s, p, 1, 8, 3, seed=500 + i, bias=bias)
         assert kern == "direct_nhwc"
+
+
+def test_large_kernel_stems_on_mfma_vs_oracle(lib, dev):
+    """conv_stem_mfma.hip: ResNet-50 7x7 s2 p3 3->64, SqueezeNet 7x7 s2 p0 3->96 + bias (odd width 109-like),
+    AlexNet 11x11 s4 p2 3->64 + bias (two k-steps per tap row), 1-channel 5x5 s1, C_out not a multiple
+    of 16, ragged last 16-pixel segment, vertical padding rows skipped."""
+    cases = [(3, 64, 64, 7, 2, 3, False), (3, 63, 96, 7, 2, 0, True), (3, 67, 64, 11, 4, 2, True),
+             (1, 40, 32, 5, 1, 2, False), (3, 37, 20, 7, 2, 3, True), (4, 33, 48, 6, 1, 1, False),
+             (3, 50, 8, 11, 4, 5, True)]
+    for i, (C, H, O, k, s, p, bias) in enumerate(cases):
+        for qbits in (8, 7):
+            kern, emax, el2 = _check_against_oracle(lib, dev, 3, C, H, O, k, s, p, 1, qbits, 0, seed=600 + i, bias=bias)
+            assert kern == ("stem_mfma_f16x1" if qbits == 8 else "stem_mfma_f16_exact"), kern
+        kern, _, _ = _check_against_oracle(lib, dev, 1, C, H, O, k, s, p, 1, 8, 3, seed=600 + i, bias=bias)
+        assert kern in ("stem_nhwc", "direct_nhwc")
 
 
 @pytest.mark.parametrize("layer", [0, 1, 2, 3, 6, 14, 17, 18])
