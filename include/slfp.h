@@ -96,7 +96,7 @@ typedef struct slfp_conv2d_desc {
 /* Validates the geometry; writes the output spatial size. */
 int slfp_conv2d_out_shape(const slfp_conv2d_desc* d, int64_t* h_out, int64_t* w_out);
 /* Which kernel family slfp_conv2d_fwd will run for this descriptor (for logs/tests):
- * a static string such as "dw3x3_nhwc", "pw_mfma_f16x3", "direct_nhwc". */
+ * a static string such as "dw3x3_nhwc", "pw_mfma_f16x3", "dense_mfma_f16x1", "direct_nhwc". */
 const char* slfp_conv2d_kernel_name(const slfp_conv2d_desc* d);
 
 /* Bytes of the prepared-weight blob for this layer (device memory the caller owns). */
@@ -108,8 +108,11 @@ size_t slfp_conv2d_wprep_bytes(const slfp_conv2d_desc* d);
  * whenever the weight tensor changes. */
 int slfp_conv2d_prepare_weights(const slfp_conv2d_desc* d, const float* w_oihw, void* wprep,
                                 float* weight_q_oihw, void* stream);
-/* Bytes of scratch slfp_conv2d_fwd needs for this descriptor (0 for the native NHWC path;
- * non-zero when a layout conversion is involved). */
+/* Bytes of scratch slfp_conv2d_fwd needs for this descriptor: 0 for the HBM-bound NHWC families
+ * (depthwise, pointwise, 3x3 stems); non-zero when a layout conversion is involved and for the
+ * two MFMA families of compute-bound layers ("dense_mfma_*": k x k with C_in >= 16,
+ * "stem_mfma_*": C_in <= 4 with KH*KW >= 25), which encode the input once to fp16 into it.
+ * The contents are scratch: nothing persists between calls. */
 size_t slfp_conv2d_workspace_bytes(const slfp_conv2d_desc* d);
 /* y = conv2d(QA(x/Ka), weight_q, bias/Ka/Kw) * Ka * Kw.
  * bias: NULL for conv2d_Q (conv2d_func.py:20-25), float32[C_out] for conv2d_Q_bias (:41-47).
