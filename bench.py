@@ -34,6 +34,7 @@ from cnns_slfp_quantization_amd import _lib, layer_specs, sharding  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 HBM_COPY_GBS = 6290.0       # measured float4-copy ceiling from the same guide
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak (same guide; never the 2:1-sparsity figure)
 
 
 class Layer:
@@ -63,6 +64,19 @@ class Layer:
         ws = L.slfp_conv2d_workspace_bytes(ctypes.byref(self.desc))  # dense k x k layers: input encoded once to fp16
         self.ws = torch.empty(ws, dtype=torch.uint8, device=dev) if ws else None
         self.bytes = spec.algorithmic_bytes(batch)
+
+    def set_passes(self, L, stream, passes):
+        """Switch the MFMA precision mode.  The prepared blob is specific to the kernel family the
+        descriptor selects (a dense k x k layer is an fp16 fragment blob in single-pass mode and a
+        float32 HWIO blob in float32-equivalent mode), so it is rebuilt when the family changes."""
+        self.desc.mfma_passes = passes
+        kernel = L.slfp_conv2d_kernel_name(ctypes.byref(self.desc)).decode()
+        if kernel != self.kernel:
+            self.kernel = kernel
+            self.blob = torch.empty(L.slfp_conv2d_wprep_bytes(ctypes.byref(self.desc)), dtype=torch.uint8, device=self.x.device)
+            ws = L.slfp_conv2d_workspace_bytes(ctypes.byref(self.desc))
+            self.ws = torch.empty(ws, dtype=torch.uint8, device=self.x.device) if ws else None
+            self.prepare(L, stream)
 
     def prepare(self, L, stream):
         _lib.check(L.slfp_conv2d_prepare_weights(ctypes.byref(self.desc), self.w.data_ptr(), self.blob.data_ptr(),
@@ -257,9 +271,10 @@ def main():
     layer_ms = [float(np.mean([ev[k][i][0].elapsed_time(ev[k][i][1]) for k in range(args.steps)])) for i in range(len(layers))]
     fam = {}
     for l, ms in zip(layers, layer_ms):
-        f = fam.setdefault(l.kernel, {"ms": 0.0, "bytes": 0, "launches": 0})
+        f = fam.setdefault(l.kernel, {"ms": 0.0, "bytes": 0, "launches": 0, "flops": 0})
         f["ms"] += ms
         f["bytes"] += l.bytes
+        f["flops"] += 2 * l.spec.macs * l.batch
         f["launches"] += 1
     dominant = max(fam, key=lambda k: fam[k]["ms"])
     dom = fam[dominant]
@@ -269,7 +284,7 @@ def main():
     exact_value = None
     if args.passes == 0:
         for l in layers:
-            l.desc.mfma_passes = _lib.MFMA_F16X3
+            l.set_passes(L, stream, _lib.MFMA_F16X3)
         step()
         torch.cuda.synchronize()
         if world > 1:
@@ -287,7 +302,7 @@ def main():
             dte = float(t.item())
         exact_value = args.batch * world * args.steps / dte
         for l in layers:
-            l.desc.mfma_passes = args.passes
+            l.set_passes(L, stream, args.passes)
 
     if rank == 0:
         imgs = args.batch * world * args.steps
@@ -313,8 +328,17 @@ def main():
                          "launches_per_step": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
                          "algorithmic_bytes_per_launch": int(dom["bytes"] / dom["launches"])},
             "kernels": {k: {"ms_per_step": round(v["ms"], 4), "GB/s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
-                            "launches": v["launches"]} for k, v in fam.items()},
+                            "TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1), "launches": v["launches"]}
+                        for k, v in fam.items()},
         }
+        if dominant.startswith(("dense_mfma", "stem_mfma")):
+            # compute-bound families (VGG-16 / ResNet-50 3x3, large stems): price against the matrix cores.
+            # achieved = algorithmic flops (2 * MACs of the layers) / measured time incl. the fp16 encode pre-pass
+            tf = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": dominant, "achieved": round(tf, 1), "peak": MFMA_F16_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": round(tf / MFMA_F16_PEAK_TFLOPS, 4), "traffic": None,
+                               "launches_per_step": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
+                               "algorithmic_flops_per_launch": int(dom["flops"] / dom["launches"])}
         if exact_value is not None:
             out["value_pointwise_f16x3_float32_equivalent"] = round(exact_value, 1)
         if args.per_layer:

@@ -8,7 +8,7 @@ namespace slfp {
 
 static size_t round256(size_t b) { return (b + 255) & ~(size_t)255; }
 
-int make_plan(const slfp_conv2d_desc* d, ConvPlan* plan) {
+static int make_plan_core(const slfp_conv2d_desc* d, ConvPlan* plan) {
     if (!d || !plan) return fail(SLFP_ERR_BAD_ARG, "conv2d: null descriptor");
     if (d->n <= 0 || d->c_in <= 0 || d->h <= 0 || d->w <= 0 || d->c_out <= 0 || d->kh <= 0 || d->kw <= 0)
         return fail(SLFP_ERR_SHAPE, "conv2d: non-positive size");
@@ -38,6 +38,8 @@ int make_plan(const slfp_conv2d_desc* d, ConvPlan* plan) {
     plan->fmt_w = d->qbits == 8 ? kFmtW8 : kFmtSfp7;
     plan->passes = d->qbits == 7 ? 1 : (d->mfma_passes == SLFP_MFMA_F16X3 ? 3 : 1);
     plan->k_pad = plan->n_pad = 0;
+    plan->repad = false;
+    plan->cpi = d->c_in; plan->cpo = d->c_out;
     plan->s1 = d->ka;
     plan->s2 = d->kw_scale;
     const int64_t cg = d->c_in / d->groups;
@@ -72,12 +74,76 @@ int make_plan(const slfp_conv2d_desc* d, ConvPlan* plan) {
     return SLFP_OK;
 }
 
+static int64_t round4(int64_t c) { return (c + 3) & ~(int64_t)3; }
+
+// The descriptor of the channel-padded launch, if this layer qualifies (see ConvPlan::repad).
+static bool padded_desc(const slfp_conv2d_desc& d, slfp_conv2d_desc* d2) {
+    if ((d.c_in % 4) == 0 && (d.c_out % 4) == 0) return false;
+    *d2 = d;
+    d2->x_layout = d2->y_layout = SLFP_LAYOUT_NHWC;
+    if (d.groups == d.c_in && d.c_out == d.c_in) {          // depthwise
+        d2->c_in = d2->c_out = round4(d.c_in);
+        d2->groups = (int32_t)d2->c_in;
+    } else if (d.groups == 1 && d.kh == 1 && d.kw == 1 && d.c_in >= 8) {  // pointwise
+        d2->c_in = round4(d.c_in);
+        d2->c_out = round4(d.c_out);
+    } else {
+        return false;
+    }
+    return true;
+}
+
+int make_plan(const slfp_conv2d_desc* d, ConvPlan* plan) {
+    int rc = make_plan_core(d, plan);
+    if (rc != SLFP_OK || plan->family != kDirect) return rc;
+    slfp_conv2d_desc d2;
+    if (!padded_desc(*d, &d2)) return rc;
+    ConvPlan inner;
+    if (make_plan_core(&d2, &inner) != SLFP_OK || (inner.family != kDw3x3 && inner.family != kPointwise)) return rc;
+    const int64_t ho = plan->h_out, wo = plan->w_out;
+    *plan = inner;
+    plan->h_out = ho; plan->w_out = wo;
+    plan->repad = true;
+    plan->cpi = d2.c_in; plan->cpo = d2.c_out;
+    return SLFP_OK;
+}
+
+// dst[row][c] = c < cs ? src[row][c] : 0 for c < cd  (channel re-padding of an NHWC tensor, either way).
+// V = floats per thread: 2 when both widths are even (58 <-> 60: 8-byte accesses), else 1.
+template <int V>
+__global__ __launch_bounds__(256) void k_repad(const float* __restrict__ src, float* __restrict__ dst, int64_t total_v,
+                                               int cs, int cd) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total_v) return;
+    const int cdv = cd / V;
+    const int64_t row = idx / cdv;
+    const int c = (int)(idx - row * cdv) * V;
+    if (V == 2) {
+        float2 v = make_float2(0.f, 0.f);
+        if (c < cs) v = *reinterpret_cast<const float2*>(src + row * cs + c);
+        *reinterpret_cast<float2*>(dst + row * cd + c) = v;
+    } else {
+        dst[idx] = c < cs ? src[row * cs + c] : 0.f;
+    }
+}
+
+static int launch_repad(const float* src, float* dst, int64_t rows, int64_t cs, int64_t cd, hipStream_t stream) {
+    if ((cs % 2) == 0 && (cd % 2) == 0) {
+        const int64_t total = rows * (cd / 2);
+        hipLaunchKernelGGL(k_repad<2>, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, stream, src, dst, total, (int)cs, (int)cd);
+    } else {
+        const int64_t total = rows * cd;
+        hipLaunchKernelGGL(k_repad<1>, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, stream, src, dst, total, (int)cs, (int)cd);
+    }
+    return check_launch("slfp channel re-pad kernel");
+}
+
 // One thread per OIHW weight element: weight_q = QW(w / Kw) (utils/conv2d_func.py:22), written
 // in the layout the selected kernel family reads.
 template <int FMT>
 __global__ __launch_bounds__(256) void k_prepare(const float* __restrict__ w, void* __restrict__ prep,
                                                  float* __restrict__ wq_oihw, int64_t total, int O, int Cg, int KH,
-                                                 int KW, const ScaleDiv sd, int family, int KS, int64_t plane) {
+                                                 int KW, const ScaleDiv sd, int family, int KS, int64_t plane, int ldo) {
     __shared__ uint32_t sT[16];
     lut_fill<FMT>(sT);
     __syncthreads();
@@ -91,7 +157,7 @@ __global__ __launch_bounds__(256) void k_prepare(const float* __restrict__ w, vo
     const int ci = (int)(r % Cg); r /= Cg;
     const int o = (int)r;
     if (family == kDw3x3) {
-        reinterpret_cast<float*>(prep)[(size_t)(kh * 3 + kw) * O + o] = q;  // [9][C]
+        reinterpret_cast<float*>(prep)[(size_t)(kh * 3 + kw) * ldo + o] = q;  // [9][C (padded)]
     } else if (family == kDirect) {
         reinterpret_cast<float*>(prep)[((size_t)(kh * KW + kw) * Cg + ci) * O + o] = q;  // [KH][KW][Cg][O]
     } else if (family == kStemMfma) {
@@ -125,7 +191,7 @@ int launch_prepare_weights(const slfp_conv2d_desc& d, const ConvPlan& p, const f
                            float* weight_q_oihw, hipStream_t stream) {
     const int Cg = (int)(d.c_in / d.groups);
     const int64_t total = d.c_out * Cg * d.kh * d.kw;
-    if (p.family == kPointwise || p.family == kDenseMfma || p.family == kStemMfma) {
+    if (p.family == kPointwise || p.family == kDenseMfma || p.family == kStemMfma || p.repad) {
         if (hipMemsetAsync(wprep, 0, p.wprep_bytes, stream) != hipSuccess) return check_launch("hipMemsetAsync(wprep)");
     }
     const int64_t plane = p.family == kStemMfma ? p.n_pad : p.k_pad * p.n_pad;
@@ -134,15 +200,19 @@ int launch_prepare_weights(const slfp_conv2d_desc& d, const ConvPlan& p, const f
     const ScaleDiv sd = make_scale_div(d.kw_scale);
     if (p.fmt_w == kFmtW8)
         hipLaunchKernelGGL((k_prepare<kFmtW8>), dim3(grid), dim3(256), 0, stream, w_oihw, wprep, weight_q_oihw, total,
-                           (int)d.c_out, Cg, (int)d.kh, (int)d.kw, sd, (int)p.family, KS, plane);
+                           (int)d.c_out, Cg, (int)d.kh, (int)d.kw, sd, (int)p.family, KS, plane, (int)p.cpo);
     else
         hipLaunchKernelGGL((k_prepare<kFmtSfp7>), dim3(grid), dim3(256), 0, stream, w_oihw, wprep, weight_q_oihw, total,
-                           (int)d.c_out, Cg, (int)d.kh, (int)d.kw, sd, (int)p.family, KS, plane);
+                           (int)d.c_out, Cg, (int)d.kh, (int)d.kw, sd, (int)p.family, KS, plane, (int)p.cpo);
     return check_launch("slfp weight prepare kernel");
 }
 
 static const char* family_name(const ConvPlan& p, const slfp_conv2d_desc& d) {
     if (p.family == kDirect && stem_applicable(d)) return "stem_nhwc";
+    if (p.repad) {  // the same kernels on channel-padded copies (ConvPlan::repad)
+        if (p.family == kDw3x3) return "repad+dw3x3_nhwc";
+        return p.fmt_act == kFmtSfp7 ? "repad+pw_mfma_f16_exact" : (p.passes == 3 ? "repad+pw_mfma_f16x3" : "repad+pw_mfma_f16x1");
+    }
     switch (p.family) {
         case kDw3x3: return "dw3x3_nhwc";
         case kPointwise: return p.fmt_act == kFmtSfp7 ? "pw_mfma_f16_exact" : (p.passes == 3 ? "pw_mfma_f16x3" : "pw_mfma_f16x1");
@@ -197,6 +267,11 @@ size_t slfp_conv2d_workspace_bytes(const slfp_conv2d_desc* d) {
     if (d->y_layout == SLFP_LAYOUT_NCHW) b += round256((size_t)d->n * d->c_out * p.h_out * p.w_out * sizeof(float));
     if (p.family == kDenseMfma) b += dense_mfma_workspace_bytes(*d);  // the input encoded once to fp16
     if (p.family == kStemMfma) b += stem_mfma_workspace_bytes(*d, p.w_out);
+    if (p.repad) {
+        if (p.cpi != d->c_in) b += round256((size_t)d->n * d->h * d->w * p.cpi * sizeof(float));
+        if (p.cpo != d->c_out) b += round256((size_t)d->n * p.h_out * p.w_out * p.cpo * sizeof(float));
+        b += 3 * round256((size_t)p.cpo * sizeof(float));  // bias / post_scale / post_shift, padded
+    }
     return b;
 }
 
@@ -241,6 +316,40 @@ int slfp_conv2d_fwd_post(const slfp_conv2d_desc* d, const float* x, const void* 
         y_nhwc = reinterpret_cast<float*>(ws);
         ws += round256((size_t)d->n * d->c_out * p.h_out * p.w_out * sizeof(float));
     }
+    if (p.repad) {
+        slfp_conv2d_desc d2;
+        padded_desc(*d, &d2);
+        const float* xin = x_nhwc;
+        float* yout = y_nhwc;
+        if (p.cpi != d->c_in) {
+            float* xp = reinterpret_cast<float*>(ws);
+            ws += round256((size_t)d->n * d->h * d->w * p.cpi * sizeof(float));
+            rc = launch_repad(x_nhwc, xp, d->n * d->h * d->w, d->c_in, p.cpi, st);
+            if (rc != SLFP_OK) return rc;
+            xin = xp;
+        }
+        if (p.cpo != d->c_out) {
+            yout = reinterpret_cast<float*>(ws);
+            ws += round256((size_t)d->n * p.h_out * p.w_out * p.cpo * sizeof(float));
+        }
+        const float* vec[3] = {bias, post_scale, post_shift};  // per-channel vectors are read 16 bytes at a time
+        for (int i = 0; i < 3; ++i) {
+            float* vp = reinterpret_cast<float*>(ws);
+            ws += round256((size_t)p.cpo * sizeof(float));
+            if (!vec[i] || p.cpo == d->c_out) continue;
+            rc = launch_repad(vec[i], vp, 1, d->c_out, p.cpo, st);
+            if (rc != SLFP_OK) return rc;
+            vec[i] = vp;
+        }
+        const PostOp post2{vec[1], vec[2], relu ? 1 : 0};
+        if (p.family == kDw3x3) rc = launch_dw3x3(d2, p, xin, reinterpret_cast<const float*>(wprep), vec[0], post2, yout, st);
+        else rc = launch_pointwise(d2, p, xin, wprep, vec[0], post2, yout, st);
+        if (rc != SLFP_OK) return rc;
+        if (p.cpo != d->c_out) rc = launch_repad(yout, y_nhwc, d->n * p.h_out * p.w_out, p.cpo, d->c_out, st);
+        if (rc != SLFP_OK) return rc;
+        if (d->y_layout == SLFP_LAYOUT_NCHW) rc = slfp_nhwc_to_nchw_f32(y_nhwc, y, d->n, d->c_out, p.h_out, p.w_out, stream);
+        return rc;
+    }
     switch (p.family) {
         case kDw3x3: rc = launch_dw3x3(*d, p, x_nhwc, reinterpret_cast<const float*>(wprep), bias, post, y_nhwc, st); break;
         case kPointwise: rc = launch_pointwise(*d, p, x_nhwc, wprep, bias, post, y_nhwc, st); break;
@@ -259,7 +368,9 @@ size_t slfp_linear_workspace_bytes(int64_t batch, int64_t in_f, int64_t out_f) {
     d.n = batch; d.c_in = in_f; d.h = 1; d.w = 1; d.c_out = out_f; d.kh = 1; d.kw = 1;
     d.stride_h = d.stride_w = d.dil_h = d.dil_w = d.groups = 1;
     d.x_layout = d.y_layout = SLFP_LAYOUT_NHWC; d.qbits = 8; d.ka = d.kw_scale = 1.f;
-    return slfp_conv2d_wprep_bytes(&d);
+    ConvPlan p;
+    if (make_plan_core(&d, &p) != SLFP_OK) return 0;  // the plan slfp_linear_fwd uses (no channel re-padding)
+    return p.wprep_bytes;
 }
 
 int slfp_linear_fwd(const float* x, const float* w, const float* bias, float* y, int64_t batch, int64_t in_f,
@@ -274,7 +385,7 @@ int slfp_linear_fwd(const float* x, const float* w, const float* bias, float* y,
     d.x_layout = d.y_layout = SLFP_LAYOUT_NHWC; d.qbits = qbits; d.ka = ka; d.kw_scale = kw_scale;
     d.mfma_passes = mfma_passes;
     ConvPlan p;
-    int rc = make_plan(&d, &p);
+    int rc = make_plan_core(&d, &p);  // no channel re-padding here: odd feature counts take the direct kernel
     if (rc != SLFP_OK) return rc;
     if (!x || !w || !y || !workspace) return fail(SLFP_ERR_BAD_ARG, "slfp_linear_fwd: null pointer");
     if (!aligned16(x) || !aligned16(y) || !aligned16(workspace) || (bias && !aligned16(bias)))

@@ -189,9 +189,15 @@ int launch_dw3x3(const slfp_conv2d_desc& d, const ConvPlan& plan, const float* x
     p.N = (int)d.n; p.H = (int)d.h; p.W = (int)d.w; p.C = (int)d.c_in;
     p.Ho = (int)plan.h_out; p.Wo = (int)plan.w_out;
     const int S = d.stride_h;
-    // channel group: largest power-of-two multiple of 4 (<= 64) dividing C
+    // channel group: largest power-of-two multiple of 4 (<= 64) dividing C; channel counts that are
+    // not a multiple of 32 (ShuffleNetV2: 24, 116, 232) get 32-wide groups with a ragged last one
+    // (masked lanes) rather than 4- or 8-channel groups whose pixels are 16-32 byte fragments
     int CB = 4;
     while (CB < 64 && p.C % (CB * 2) == 0) CB *= 2;
+    if (CB < 32) {
+        CB = 4;
+        while (CB < 32 && CB < p.C) CB *= 2;
+    }
     const int tmax = (S == 1) ? 14 : 7;
     p.TH = p.Ho < tmax ? p.Ho : tmax;
     p.TW = p.Wo < tmax ? p.Wo : tmax;
@@ -204,7 +210,7 @@ int launch_dw3x3(const slfp_conv2d_desc& d, const ConvPlan& plan, const float* x
     p.CB = CB;
     p.cb4_shift = 0;
     while ((4 << p.cb4_shift) < CB) ++p.cb4_shift;
-    p.cgroups = p.C / CB;
+    p.cgroups = (int)ceil_div(p.C, CB);
     p.pad = d.pad_h;
     p.IWh = (p.IW + 1) / 2;
     const int dp = kDwThreads >> p.cb4_shift;

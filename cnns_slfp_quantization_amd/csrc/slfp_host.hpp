@@ -45,6 +45,13 @@ struct ConvPlan {
     // pointwise: padded K (multiple of 64) and N (multiple of 64) of the fragment-ordered blob
     int64_t k_pad, n_pad;
     size_t wprep_bytes;
+    // Channel counts that are not a multiple of 4 (ShuffleNetV2's 58-channel branches) break the
+    // 16-byte NHWC access the depthwise / pointwise kernels are built on.  Such layers run those
+    // same kernels on channel-padded copies: x -> [..][cpi] (zeros appended: Q(0) = 0 and the
+    // padded weights are 0, so results are unchanged), y <- [..][cpo].  `family` etc. describe
+    // the inner (padded) launch.
+    bool repad;
+    int64_t cpi, cpo;
 };
 
 // Validates `d` and fills `plan`; returns SLFP_OK or an error status (error text recorded).

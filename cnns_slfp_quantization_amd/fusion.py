@@ -37,8 +37,6 @@ def fuse_pair(conv, bn=None, relu=False):
     if bn is not None:
         if bn.num_features != conv.out_channels:
             raise ValueError("fuse_pair: BatchNorm2d width does not match the conv's out_channels")
-        if conv.out_channels % 4:
-            raise ValueError("fuse_pair: out_channels must be a multiple of 4 for the fused epilogue")
         scale, shift = fold_bn(bn)
         dev = conv.weight.device
         conv._post = (scale.to(dev), shift.to(dev), bool(relu))
@@ -59,7 +57,7 @@ def fuse_bn_relu(model):
             if _is_conv_q(conv) and conv._post is None and i + 1 < len(names):
                 bn = seq._modules[names[i + 1]]
                 ok = (isinstance(bn, nn.BatchNorm2d) and not bn.training and bn.num_features == conv.out_channels
-                      and conv.out_channels % 4 == 0 and (conv.bias is None or getattr(conv, "_scaled_bias", False)))
+                      and (conv.bias is None or getattr(conv, "_scaled_bias", False)))
                 if ok:
                     relu = i + 2 < len(names) and isinstance(seq._modules[names[i + 2]], nn.ReLU)
                     fuse_pair(conv, bn, relu)

@@ -45,6 +45,11 @@ class ConvSpec:
     def macs(self):
         return self.out_elems * (self.c_in // self.groups) * self.k[0] * self.k[1]
 
+    @property
+    def macs(self):
+        """Multiply-accumulates per image."""
+        return self.h_out * self.w_out * self.c_out * (self.c_in // self.groups) * self.k[0] * self.k[1]
+
     def algorithmic_bytes(self, batch):
         """fp32 activations read once, fp32 outputs written once, fp32 weights
         read once per batch."""

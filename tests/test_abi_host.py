@@ -39,7 +39,12 @@ def test_kernel_selection_and_sizes():
     name = lambda d: L.slfp_conv2d_kernel_name(ctypes.byref(d)).decode()
     assert name(_desc()) == "dw3x3_nhwc"
     assert name(_desc(stride_h=2, stride_w=2)) == "dw3x3_nhwc"
-    assert name(_desc(c_in=58, c_out=58, groups=58)) == "direct_nhwc"          # ShuffleNetV2 odd width
+    odd = _desc(c_in=58, c_out=58, groups=58)                                    # ShuffleNetV2 odd width:
+    assert name(odd) == "repad+dw3x3_nhwc"                                       # same kernel on channel-padded copies
+    assert L.slfp_conv2d_wprep_bytes(ctypes.byref(odd)) == 2304                  # 9*60*4 rounded up to 256
+    assert L.slfp_conv2d_workspace_bytes(ctypes.byref(odd)) == 2 * (2 * 16 * 16 * 60 * 4) + 3 * 256
+    assert name(_desc(c_in=58, c_out=58, groups=1, kh=1, kw=1, pad_h=0, pad_w=0)) == "repad+pw_mfma_f16x1"
+    assert name(_desc(c_in=58, c_out=58, groups=2)) == "direct_nhwc"             # grouped, not depthwise
     pw = _desc(kh=1, kw=1, pad_h=0, pad_w=0, groups=1, c_in=128, c_out=256)
     assert name(pw) == "pw_mfma_f16x1"                                           # default: one fp16 pass
     pw.mfma_passes = _lib.MFMA_F16X3
@@ -192,18 +197,18 @@ def test_fuse_bn_relu_host_logic():
     Cb = cf.conv2d_Q_bias(32, 0.1, 0.2)
     m = nn.Sequential(C(8, 16, 3, 0.1, 0.2, 1, 1), nn.BatchNorm2d(16), nn.ReLU(inplace=True),
                       Cb(16, 16, 1, 0.1, 0.2), nn.BatchNorm2d(16),
-                      C(16, 6, 1, 0.1, 0.2), nn.BatchNorm2d(6), nn.ReLU()).eval()   # 6 channels: not fusable (% 4)
+                      C(16, 6, 1, 0.1, 0.2), nn.BatchNorm2d(6), nn.ReLU()).eval()   # 6 channels: any width fuses
     for b in (m[1], m[4], m[6]):
         b.running_mean.normal_(); b.running_var.uniform_(0.5, 1.5); b.weight.data.uniform_(0.5, 1.5); b.bias.data.normal_()
     x = torch.randn(2, 8, 6, 6)
     with torch.no_grad():
         y0 = m(x)
-        assert fusion.fuse_bn_relu(m) == 2
-        assert [type(c).__name__ for c in m] == ["Conv2d_Q", "Identity", "Identity", "Conv2d_Q", "Identity", "Conv2d_Q", "BatchNorm2d", "ReLU"]
+        assert fusion.fuse_bn_relu(m) == 3
+        assert [type(c).__name__ for c in m] == ["Conv2d_Q", "Identity", "Identity", "Conv2d_Q", "Identity", "Conv2d_Q", "Identity", "Identity"]
         assert m[0]._post[2] is True and m[3]._post[2] is False
         y1 = m(x)
         assert torch.allclose(y0, y1, rtol=1e-5, atol=1e-5)
-        assert fusion.unfuse(m) == 2 and isinstance(m[1], nn.BatchNorm2d) and m[0]._post is None
+        assert fusion.unfuse(m) == 3 and isinstance(m[1], nn.BatchNorm2d) and isinstance(m[6], nn.BatchNorm2d) and m[0]._post is None
         assert torch.equal(m(x), y0)
     m.train()
     with pytest.raises(RuntimeError):

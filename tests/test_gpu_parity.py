@@ -327,6 +327,22 @@ def test_dense_kxk_mfma_vs_oracle(lib, dev):
         assert kern == "direct_nhwc"
 
 
+def test_channel_counts_not_multiple_of_4_vs_oracle(lib, dev):
+    """ShuffleNetV2's 58-channel branches (nets_imgnet/shufflenetv2.py): depthwise and 1x1 layers whose channel
+    count is not a multiple of 4 run the fast kernels on channel-padded copies; 24/116/232-channel depthwise
+    layers use 32-wide channel groups with a ragged last group."""
+    cases = [(58, 28, 58, 3, 1, 1, 58, False), (58, 29, 58, 3, 2, 1, 58, True), (58, 28, 58, 1, 1, 0, 1, False),
+             (24, 28, 58, 1, 1, 0, 1, True), (58, 14, 116, 1, 1, 0, 1, False), (30, 9, 30, 3, 1, 1, 30, True),
+             (24, 30, 24, 3, 2, 1, 24, False), (116, 15, 116, 3, 1, 1, 116, False), (232, 14, 232, 3, 2, 1, 232, True)]
+    for i, (C, H, O, k, s, p, g, bias) in enumerate(cases):
+        for qbits, passes in ((8, 0), (8, 3), (7, 0)):
+            kern, emax, el2 = _check_against_oracle(lib, dev, 3, C, H, O, k, s, p, g, qbits, passes, seed=700 + i, bias=bias)
+            if C % 4 or O % 4:
+                assert kern.startswith("repad+"), kern
+            else:
+                assert kern == "dw3x3_nhwc", kern
+
+
 def test_large_kernel_stems_on_mfma_vs_oracle(lib, dev):
     """conv_stem_mfma.hip: ResNet-50 7x7 s2 p3 3->64, SqueezeNet 7x7 s2 p0 3->96 + bias (odd width 109-like),
     AlexNet 11x11 s4 p2 3->64 + bias (two k-steps per tap row), 1-channel 5x5 s1, C_out not a multiple
@@ -507,7 +523,9 @@ def test_fused_bn_relu_epilogue_matches_stock_modules(dev):
     g = torch.Generator(device="cpu").manual_seed(5)
     cases = [(C(3, 32, 3, Kw, Ka, 2, 1), 3, 33), (C(64, 64, 3, Kw, Ka, 1, 1, groups=64), 64, 20),
              (C(64, 64, 3, Kw, Ka, 2, 1, groups=64), 64, 21), (C(64, 128, 1, Kw, Ka), 64, 14), (C(256, 512, 1, Kw, Ka), 256, 9),
-             (C(16, 32, 3, Kw, Ka, 1, 1), 16, 12), (Cb(16, 32, 3, Kw, Ka, 1, 1), 16, 12)]
+             (C(16, 32, 3, Kw, Ka, 1, 1), 16, 12), (Cb(16, 32, 3, Kw, Ka, 1, 1), 16, 12),
+             # channel counts that are not a multiple of 4: the channel-re-padded launches (bias / BN vectors padded too)
+             (C(58, 58, 3, Kw, Ka, 1, 1, groups=58), 58, 13), (Cb(24, 58, 1, Kw, Ka), 24, 13), (C(3, 64, 7, Kw, Ka, 2, 3), 3, 40)]
     try:
         for passes in (3, 0):
             cf.options.mfma_passes = passes
