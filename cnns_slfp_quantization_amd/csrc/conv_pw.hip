@@ -30,7 +30,13 @@
 //                ch, 8 waves, 126 VGPRs).  Tried and dropped: deeper X register rings, W
 //                double-buffering (vmcnt retires in order: a W wait drains younger-issued X
 //                loads anyway), a warp-specialised producer/consumer variant (no faster;
-//                MT = 7 tiles spill at the 168-VGPR cap of a 12-wave workgroup).
+//                MT = 7 tiles spill at the 168-VGPR cap of a 12-wave workgroup), and an
+//                "X-stationary" variant that separates the phases in time (whole 64 px x K tile
+//                burst-loaded and parked in LDS as fp16, then an MFMA sweep with only L2 W loads,
+//                two workgroups per CU, optionally persistent with the second resident started
+//                half a period late): 0.082 ms non-persistent, 0.097 ms persistent+staggered vs
+//                0.076 ms for this kernel on 512->512 @14x14 -- all CUs burst, encode, multiply
+//                and store in lockstep and the start offset does not survive the first tile.
 // Operand precision: SFP<3,3> values are exact in fp16 (1 pass, exact products).
 // SLFP<3,4> values are 2^(m/16) multiples; fp16x1 rounds them to 11 bits (~2.5e-4
 // tensor-relative error), fp16x3 splits both operands hi+lo (3 MFMA passes,
