@@ -23,7 +23,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def short(name):
     m = re.search(r"slfp::(k_[a-z0-9_]+)(<[^>]*>)?", name)
-    return (m.group(1) + (m.group(2) or "")) if m else None
+    if m:
+        return m.group(1) + (m.group(2) or "")
+    # kernels with a _Float16 parameter come back mangled: _ZN4slfp14k_dense_encodeILi0EEEv...
+    m = re.search(r"_ZN4slfp\d+(k_[a-z0-9_]+?)I((?:Li\d+E)+)E", name)
+    if m:
+        return m.group(1) + "<" + ", ".join(re.findall(r"Li(\d+)E", m.group(2))) + ">"
+    return None
 
 
 def load_counters(d):
@@ -57,6 +63,7 @@ def load_trace(d):
 
 def main():
     tag = sys.argv[1]
+    what = sys.argv[2] if len(sys.argv) > 2 else "MobileNetV1-224 SLFP<3,4>, batch 256"
     base = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     dur = load_trace(os.path.join(base, "stats"))
     counters = {}
@@ -102,7 +109,7 @@ def main():
     cols = ["kernel", "grid_threads", "launches", "avg_us", "vgpr", "agpr", "lds", "hbm_read_MB", "hbm_write_MB", "hbm_GBps",
             "valu_active_frac", "wait_any_frac", "lds_conflict_frac", "valu_insts_per_wave"]
     with open(os.path.join(ROOT, "profiles", f"{tag}_summary.md"), "w") as f:
-        f.write(f"# rocprofv3 summary `{tag}` (bench.py, MobileNetV1-224 SLFP<3,4>, batch 256, 1x MI355X)\n\n")
+        f.write(f"# rocprofv3 summary `{tag}` (bench.py, {what}, 1x MI355X)\n\n")
         f.write("Source: `profiles/run_profile.sh` (kernel-trace --stats pass + separate --pmc passes). "
                 "hbm_read_MB = 2 x FETCH_SIZE (gfx950 correction), hbm_write_MB = WRITE_SIZE.\n\n")
         f.write("| " + " | ".join(cols) + " |\n|" + "---|" * len(cols) + "\n")
