@@ -55,9 +55,14 @@ struct DenseParams {
 };
 
 __device__ __forceinline__ uint32_t dn_x_off(int row, int chunk16) {
-    // 128-byte rows: a 16-lane fragment read touches 16 consecutive rows; (row & 1) picks the
-    // 128-byte half of the 256-byte bank line, (row >> 1) & 7 rotates the 16-byte slot -> 16 distinct slots
-    return (uint32_t)row * 128u + (uint32_t)((chunk16 ^ ((row >> 1) & 7)) << 4);
+    // 128-byte rows; a fragment read touches 16 rows base .. base+15 for ANY base (taps shift it).
+    // ds_read_b128 is served in lane groups {0-3,12-15,20-27}, ... = 8 lanes of an even lane-quarter
+    // (rows +0..3, +12..15) and 8 of the next odd one (rows +4..11): bit 0 of the chunk (= parity of
+    // the lane-quarter) is left alone so the two halves of a group never meet; bits 1-2 are rotated
+    // by (row >> 1) & 3, which takes 4 distinct values on each half's 4 same-parity rows; (row & 1)
+    // picks the 128-byte half of the 256-byte bank line.  16 distinct slots per group (profiles/
+    // r01f_vgg16 measured 18 % conflict cycles with the plain (row >> 1) & 7 rotation).
+    return (uint32_t)row * 128u + (uint32_t)((chunk16 ^ (((row >> 1) & 3) << 1)) << 4);
 }
 
 __device__ __forceinline__ void glds16(const void* g, void* l) {  // 64 lanes x 16 B -> 1 KiB of LDS at (wave-uniform) l
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(kDnThreads, (MT == 4 ? 2 : 4)) void k_dense_mfma(co
         const int pix = pc * 8 + (lane >> 3);
         const int ih = pix / p.IW, iw = pix - ih * p.IW;
         const int gh = h_in0 + ih, gw = w_in0 + iw;
-        const int c16 = (lane & 7) ^ ((pix >> 1) & 7);            // source chunk for this slot (dn_x_off's swizzle)
+        const int c16 = (lane & 7) ^ (((pix >> 1) & 3) << 1);     // source chunk for this slot (dn_x_off's swizzle)
         const int kbyte = chunk * 128 + c16 * 16;
         const bool inb = pix < p.n_pix && (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W && kbyte < p.Cp * 2;
         const unsigned char* src = inb ? xen + ((size_t)(gh * p.W + gw) * p.Cp) * 2 + kbyte : p.zero_page + (lane & 7) * 16;
