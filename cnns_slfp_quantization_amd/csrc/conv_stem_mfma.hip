@@ -57,13 +57,21 @@ __global__ __launch_bounds__(256) void k_stem_im2row(const float* __restrict__ x
     const int64_t row = run / Wo;                       // n*H + ih
     const float* xr = x + row * (int64_t)W * C;
     const int e0 = (ow * S - pw) * C + cj * 8;          // element offset inside the input row
-    half8 h;
+    half8 h = half8{0, 0, 0, 0, 0, 0, 0, 0};
+    if (cj * 8 < RL) {                                   // chunks that are all padding just store zeros
+        const int last = W * C - 1;
+        float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int r = cj * 8 + j, e = e0 + j;
-        float v = 0.f;
-        if (r < RL && e >= 0 && e < W * C) v = quantize_scaled<FMT, 4>(xr[e], sd, sT);
-        h[j] = (_Float16)v;
+        for (int j = 0; j < 8; ++j) {                    // unconditional (clamped) loads: all 8 in flight
+            const int e = e0 + j;
+            v[j] = xr[e < 0 ? 0 : (e > last ? last : e)];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = cj * 8 + j, e = e0 + j;
+            const float q = quantize_scaled<FMT, 4>(v[j], sd, sT);
+            h[j] = (_Float16)((r < RL && e >= 0 && e <= last) ? q : 0.f);
+        }
     }
     *reinterpret_cast<half8*>(xe + idx * 8) = h;
 }
@@ -82,8 +90,14 @@ __global__ __launch_bounds__(kSmThreads, 2) void k_stem_mfma(const StemMfmaParam
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 15, kq = lane >> 4;
     const int ksub = 1 << (p.rp_shift - 5);
-    const int64_t stride = (int64_t)gridDim.x * (kSmThreads / 64);
-    for (int64_t u = (int64_t)blockIdx.x * (kSmThreads / 64) + wave; u < p.units; u += stride) {
+    // a workgroup owns a CONTIGUOUS range of (image, output row, 16-pixel segment) units: its 8 waves
+    // sweep a row's segments together and move down row by row, so the KH/S re-reads of every
+    // im2row line come from this CU's L1 / this XCD's L2 (r01f_resnet50: a strided assignment
+    // re-fetched the fp16 image 3.3x through the fabric)
+    const int64_t chunk = (p.units + gridDim.x - 1) / gridDim.x;
+    const int64_t u_begin = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * chunk;
+    const int64_t u_end = u_begin + chunk < p.units ? u_begin + chunk : p.units;
+    for (int64_t u = u_begin + wave; u < u_end; u += kSmThreads / 64) {
         const int seg = (int)(u % p.segs);
         const int64_t t = u / p.segs;
         const int oh = (int)(t % p.Ho);
