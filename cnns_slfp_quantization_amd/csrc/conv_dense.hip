@@ -156,40 +156,58 @@ __global__ __launch_bounds__(kDnThreads, (MT == 4 ? 2 : 4)) void k_dense_mfma(co
         for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
     const int n_chunks = p.KS >> 1, n_taps = p.KH * p.KW;
+    const int n_steps = n_chunks * n_taps;
     stage_w(0, 0, 0);
+    if (n_steps > 1) stage_w(n_taps > 1 ? 1 : 0, n_taps > 1 ? 0 : 1, 1);
     for (int pc = wave; pc < p.x_pieces; pc += 8) stage_x(pc, 0, 0);
     __syncthreads();
 
+    // Per tap: (1) this tap's fragments LDS -> registers; (2) barrier (every wave has read wbuf[wb],
+    // and the DMAs issued one tap ago have landed: vmcnt(0)); (3) the DMA for tap+2 goes into the
+    // buffer just freed, plus a slice of the next chunk's halo; (4) the MFMAs run from registers while
+    // those DMAs fly.  Two weight buffers give a two-tap flight window because the operands of the
+    // tap in progress live in registers.
     int wb = 0, xb = 0;
     for (int chunk = 0; chunk < n_chunks; ++chunk) {
         const bool more_chunks = chunk + 1 < n_chunks;
         const unsigned char* xs = xsb + (size_t)xb * xbytes;
         for (int tap = 0; tap < n_taps; ++tap) {
-            const bool last_tap = tap + 1 == n_taps;
-            // next weight tile (next tap, or tap 0 of the next chunk) and a slice of the next chunk's halo
-            if (!last_tap || more_chunks) stage_w(last_tap ? 0 : tap + 1, last_tap ? chunk + 1 : chunk, wb ^ 1);
-            if (more_chunks) {
+            const int kh = tap / p.KW, kw = tap - kh * p.KW;
+            const unsigned char* wt = wbuf + (size_t)wb * WT + (size_t)(wn * 4) * 2048 + lane * 16;
+            half8 wf[2][4], xf[2][MT];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wf[ks][j] = *reinterpret_cast<const half8*>(wt + j * 2048 + ks * 1024);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int row = ((wm * MT + i) * p.S + kh) * p.IW + col * p.S + kw;
+                    xf[ks][i] = *reinterpret_cast<const half8*>(xs + dn_x_off(row, ks * 4 + kq));
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            // the weight tile two taps ahead -> the buffer every wave has just finished reading
+            int tap2 = tap + 2, chunk2 = chunk;
+            if (tap2 >= n_taps) { tap2 -= n_taps; ++chunk2; }
+            if (tap2 >= n_taps) { tap2 -= n_taps; ++chunk2; }   // single-tap-row kernels (n_taps == 1 cannot occur)
+            if (chunk2 < n_chunks) stage_w(tap2, chunk2, wb);
+            // a slice of the next chunk's halo; nothing on the last tap: its DMA would still be in flight
+            // when the next chunk's first fragments are read
+            if (more_chunks && tap + 1 < n_taps) {
                 for (int q = 0; q < p.x_per_tap; ++q) {
                     const int pc = (tap * p.x_per_tap + q) * 8 + wave;
                     if (pc < p.x_pieces) stage_x(pc, chunk + 1, xb ^ 1);
                 }
             }
-            const int kh = tap / p.KW, kw = tap - kh * p.KW;
-            const unsigned char* wt = wbuf + (size_t)wb * WT + (size_t)(wn * 4) * 2048 + lane * 16;
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                half8 wf[4];
+            for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const half8*>(wt + j * 2048 + ks * 1024);
+                for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int i = 0; i < MT; ++i) {
-                    const int row = ((wm * MT + i) * p.S + kh) * p.IW + col * p.S + kw;
-                    const half8 xf = *reinterpret_cast<const half8*>(xs + dn_x_off(row, ks * 4 + kq));
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf, acc[i][j], 0, 0, 0);
-                }
-            }
-            __syncthreads();  // drains this tap's DMAs (vmcnt(0)); every wave is done with wbuf[wb]
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][j], xf[ks][i], acc[i][j], 0, 0, 0);
             wb ^= 1;
         }
         xb ^= 1;
@@ -234,7 +252,7 @@ static bool dense_cfg_geometry(const slfp_conv2d_desc& d, const DenseCfg& c, Den
     g->ih = (th - 1) * S + (int)d.kh;
     g->iw = (kDnTW - 1) * S + (int)d.kw;
     g->pieces = (g->ih * g->iw + 7) / 8;
-    g->per_tap = (int)ceil_div(ceil_div(g->pieces, 8), taps);
+    g->per_tap = (int)ceil_div(ceil_div(g->pieces, 8), taps - 1);  // all slices issued before the last tap
     g->lds = 2 * (size_t)c.wn * 64 * 128 + 2 * (size_t)g->pieces * 1024;
     // MT 4 tilings hold 64 accumulator VGPRs + fragments: compiled for one workgroup per CU; the others for two
     g->occ = c.mt == 4 ? 1 : (g->lds <= 80 * 1024 ? 2 : 1);
