@@ -40,14 +40,14 @@ MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak (same guide; never th
 class Layer:
     """One Conv2d_Q layer of the workload, bound to device buffers."""
 
-    def __init__(self, L, spec, batch, dev, passes, gen, rank0_weights=True):
+    def __init__(self, L, spec, batch, dev, passes, gen, qbits=8):
         self.spec = spec
         self.batch = batch
         s = spec
         self.desc = _lib.ConvDesc(n=batch, c_in=s.c_in, h=s.h, w=s.w, c_out=s.c_out, kh=s.k[0], kw=s.k[1],
                                   stride_h=s.stride[0], stride_w=s.stride[1], pad_h=s.pad[0], pad_w=s.pad[1],
                                   dil_h=1, dil_w=1, groups=s.groups, x_layout=_lib.LAYOUT_NHWC,
-                                  y_layout=_lib.LAYOUT_NHWC, qbits=8, ka=float(np.float32(s.Ka)),
+                                  y_layout=_lib.LAYOUT_NHWC, qbits=qbits, ka=float(np.float32(s.Ka)),
                                   kw_scale=float(np.float32(s.Kw)), mfma_passes=passes, reserved=0)
         self.kernel = L.slfp_conv2d_kernel_name(ctypes.byref(self.desc)).decode()
         # synthetic post-ReLU-like activation spanning all 7 binades and both clamps (SURVEY 8d);
@@ -201,6 +201,7 @@ def main():
     ap.add_argument("--net", default="mobilenetv1_imagenet224")
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
     ap.add_argument("--passes", type=int, default=0, choices=[0, 1, 3], help="pointwise MFMA precision (0 = library default)")
+    ap.add_argument("--qbits", type=int, default=8, choices=[8, 7], help="8 = SLFP<3,4> (headline), 7 = SFP<3,3> (BASELINE config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-whole-net", action="store_true")
     ap.add_argument("--cpu-sample-batch", type=int, default=16)
@@ -223,7 +224,7 @@ def main():
 
     specs = layer_specs.conv_layers(args.net)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    layers = [Layer(L, s, args.batch, dev, args.passes, gen) for s in specs]
+    layers = [Layer(L, s, args.batch, dev, args.passes, gen, args.qbits) for s in specs]
     stream = torch.cuda.current_stream().cuda_stream
 
     # quantize the weights ONCE on rank 0 and broadcast the prepared blobs as one bucket
@@ -282,7 +283,7 @@ def main():
 
     # ---- the float32-equivalent pointwise mode (fp16 hi/lo split, 3 MFMA passes), same buffers
     exact_value = None
-    if args.passes == 0:
+    if args.passes == 0 and args.qbits == 8:
         for l in layers:
             l.set_passes(L, stream, _lib.MFMA_F16X3)
         step()
@@ -314,7 +315,8 @@ def main():
             "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 (1x1 contraction: fp16 MFMA operands, f32 accumulate)", "data": "synthetic",
-            "config": {"workload": f"{args.net}: all {len(layers)} Conv2d_Q layers, SLFP<3,4> Qbits=8, NHWC, "
+            "config": {"workload": f"{args.net}: all {len(layers)} Conv2d_Q layers, "
+                                   f"{'SLFP<3,4> Qbits=8' if args.qbits == 8 else 'SFP<3,3> Qbits=7'}, NHWC, "
                                    f"batch {args.batch} per GPU, inputs resident in HBM",
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"batch-sharded x{world}, one-time RCCL weight broadcast",
