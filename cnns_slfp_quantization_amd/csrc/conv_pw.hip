@@ -434,20 +434,12 @@ static int launch_pw(PwParams& p, const ConvPlan& plan, hipStream_t stream) {
         if (p.N > 64) return launch_tiled<FMT, 3, 2, 2, 2, 4>(p, stream);   // 64 px x 128 ch
         return launch_tiled<FMT, 3, 4, 1, 1, 4>(p, stream);                  // 64 px x  64 ch
     } else {
-        // widest channel tile (fewest re-reads / re-encodes of X) that still yields >= 1.2 workgroups
-        // per CU: the small-M, deep-K layers of ResNet-50's last stages (7x7 / 14x14 images at
-        // batch 64: 49-196 pixel tiles) otherwise leave most of the chip idle
-        const int64_t m_tiles = ceil_div(p.M, 64);
-        auto blocks = [&](int bn) { return m_tiles * ceil_div((int64_t)p.N, bn); };
-        const int64_t want = 300;
-        if (p.N > 256 && blocks(512) >= want) return launch_tiled<FMT, 1, 1, 8, 4, 4>(p, stream);  // 64 px x 512 ch, 8 waves
-        if (p.N > 128 && blocks(256) >= want) return launch_tiled<FMT, 1, 1, 4, 4, 4>(p, stream);  // 64 px x 256 ch
-        if (p.N > 64 && blocks(128) >= want) return launch_tiled<FMT, 1, 2, 2, 2, 4>(p, stream);   // 64 px x 128 ch
-        if (p.N > 64 && blocks(64) < want) {  // nothing fills the chip: take the tile with the least redundant work
-            if (p.N > 256) return launch_tiled<FMT, 1, 1, 8, 4, 4>(p, stream);
-            if (p.N > 128) return launch_tiled<FMT, 1, 1, 4, 4, 4>(p, stream);
-            return launch_tiled<FMT, 1, 2, 2, 2, 4>(p, stream);
-        }
+        // widest channel tile: fewest re-reads / re-encodes of X.  (Narrower tiles for the small-M, deep-K
+        // layers of ResNet-50's last stages -- 49-196 pixel tiles at batch 64 -- were measured: more
+        // workgroups, but the redundant encode costs more than the idle CUs did.)
+        if (p.N > 256) return launch_tiled<FMT, 1, 1, 8, 4, 4>(p, stream);  // 64 px x 512 ch, 8 waves, 2 workgroups/CU
+        if (p.N > 128) return launch_tiled<FMT, 1, 1, 4, 4, 4>(p, stream);  // 64 px x 256 ch
+        if (p.N > 64) return launch_tiled<FMT, 1, 2, 2, 2, 4>(p, stream);   // 64 px x 128 ch
         return launch_tiled<FMT, 1, 4, 1, 1, 4>(p, stream);                  // 64 px x  64 ch
     }
 }
