@@ -50,7 +50,10 @@ static int make_plan_core(const slfp_conv2d_desc* d, ConvPlan* plan) {
         plan->family = kDw3x3;
         plan->wprep_bytes = round256((size_t)9 * d->c_in * sizeof(float));
     } else if (d->kh == 1 && d->kw == 1 && d->groups == 1 && d->pad_h == 0 && d->pad_w == 0 && sq_stride &&
-               (d->c_in % 4) == 0 && (d->c_out % 4) == 0) {
+               (((d->c_in % 4) == 0 && (d->c_out % 4) == 0) ||
+                // even channel counts (ShuffleNetV2: 58): the LDS-resident stream kernel with 8-byte accesses
+                ((d->c_in % 2) == 0 && (d->c_out % 2) == 0 && d->c_in >= 8 &&
+                 pointwise_stream_fits(ceil_div(d->c_in, 64) * 64, ceil_div(d->c_out, 64) * 64, plan->passes)))) {
         plan->family = kPointwise;
         plan->k_pad = ceil_div(d->c_in, 64) * 64;
         plan->n_pad = ceil_div(d->c_out, 64) * 64;

@@ -115,14 +115,25 @@ __device__ __forceinline__ float4 bias_q256(const PwParams& p, int n) {
                        256.f * ((bb.z / p.s1) / p.s2), 256.f * ((bb.w / p.s1) / p.s2));
 }
 
+// 4 consecutive per-channel values starting at channel n (even) of an N-long vector (N even), read as
+// two 8-byte halves; channels >= N come back as 0.  For channel counts that are not a multiple of 4.
+__device__ __forceinline__ float4 load4_even(const float* v, int n, int N) {
+    float2 a = make_float2(0.f, 0.f), b = a;
+    if (n < N) a = *reinterpret_cast<const float2*>(v + n);
+    if (n + 2 < N) b = *reinterpret_cast<const float2*>(v + n + 2);
+    return make_float4(a.x, a.y, b.x, b.y);
+}
+
 // ======================================================================================
 // k_pw_stream: W resident in LDS, X straight into MFMA fragments, 16-pixel work units.
 // ======================================================================================
 constexpr int kStreamThreads = 512;
 
 // KS = number of 32-deep k-steps actually swept (ceil(K/32)); the blob's stride is p.KS.
-// KFULL: K is a multiple of 32.
-template <int FMT, int PASSES, int KS, bool KFULL>
+// KFULL: K is a multiple of 32.  A8: K and N are even but not both multiples of 4 (ShuffleNetV2's
+// 58-channel branches): pixel rows are only 8-byte aligned, so every 16-byte access becomes two
+// 8-byte ones and the per-channel vectors are read with bounds.
+template <int FMT, int PASSES, int KS, bool KFULL, bool A8 = false>
 __global__ __launch_bounds__(kStreamThreads) void k_pw_stream(const PwParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* sT = reinterpret_cast<uint32_t*>(smem);
@@ -160,7 +171,15 @@ __global__ __launch_bounds__(kStreamThreads) void k_pw_stream(const PwParams p) 
             for (int c = 0; c < CH; ++c) {
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
-                    if constexpr (KFULL) {
+                    if constexpr (A8) {
+                        const int k = (c0 + c) * 32 + hf * 16 + kq * 4;   // K is even: each 8-byte half is all real or all padding
+                        const float* row = xr - kq * 4;
+                        float2 a = *reinterpret_cast<const float2*>(row + (k < p.K ? k : p.K - 2));
+                        float2 b = *reinterpret_cast<const float2*>(row + (k + 2 < p.K ? k + 2 : p.K - 2));
+                        if (k >= p.K) a = make_float2(0.f, 0.f);
+                        if (k + 2 >= p.K) b = make_float2(0.f, 0.f);
+                        raw[c][hf] = make_float4(a.x, a.y, b.x, b.y);
+                    } else if constexpr (KFULL) {
                         raw[c][hf] = *reinterpret_cast<const float4*>(xr + (c0 + c) * 32 + hf * 16);
                     } else {
                         const int k = (c0 + c) * 32 + hf * 16 + kq * 4;
@@ -197,8 +216,26 @@ __global__ __launch_bounds__(kStreamThreads) void k_pw_stream(const PwParams p) 
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[ks], acc, 0, 0, 0);
             }
             const int n = j * 16 + kq * 4;
-            if (live && n < p.N)
-                *reinterpret_cast<float4*>(yr + j * 16) = post_apply(epilogue(acc, bias_q256(p, n), p.s1x, p.s2), p.post, n);
+            if constexpr (A8) {
+                float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.bias) {
+                    const float4 bb = load4_even(p.bias, n, p.N);
+                    bq = make_float4(256.f * ((bb.x / p.s1) / p.s2), 256.f * ((bb.y / p.s1) / p.s2),
+                                     256.f * ((bb.z / p.s1) / p.s2), 256.f * ((bb.w / p.s1) / p.s2));
+                }
+                float4 r = epilogue(acc, bq, p.s1x, p.s2);
+                if (p.post.scale) {
+                    const float4 sc = load4_even(p.post.scale, n, p.N), sh = load4_even(p.post.shift, n, p.N);
+                    r.x = __builtin_fmaf(r.x, sc.x, sh.x); r.y = __builtin_fmaf(r.y, sc.y, sh.y);
+                    r.z = __builtin_fmaf(r.z, sc.z, sh.z); r.w = __builtin_fmaf(r.w, sc.w, sh.w);
+                }
+                if (p.post.relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+                if (live && n < p.N) *reinterpret_cast<float2*>(yr + j * 16) = make_float2(r.x, r.y);
+                if (live && n + 2 < p.N) *reinterpret_cast<float2*>(yr + j * 16 + 2) = make_float2(r.z, r.w);
+            } else {
+                if (live && n < p.N)
+                    *reinterpret_cast<float4*>(yr + j * 16) = post_apply(epilogue(acc, bias_q256(p, n), p.s1x, p.s2), p.post, n);
+            }
         }
     }
 }
@@ -396,7 +433,8 @@ static int launch_tiled(PwParams& p, hipStream_t stream) {
 template <int FMT, int PASSES, int KS>
 static int launch_stream_ks(PwParams& p, hipStream_t stream) {
     const size_t lds = 64 + (size_t)(PASSES == 3 ? 2 : 1) * p.n_tiles * p.KS * 1024;
-    auto fn = (p.K % 32 == 0) ? k_pw_stream<FMT, PASSES, KS, true> : k_pw_stream<FMT, PASSES, KS, false>;
+    auto fn = (p.K % 4 || p.N % 4) ? k_pw_stream<FMT, PASSES, KS, false, true>
+              : (p.K % 32 == 0)    ? k_pw_stream<FMT, PASSES, KS, true> : k_pw_stream<FMT, PASSES, KS, false>;
     int rc = set_lds_limit(reinterpret_cast<const void*>(fn), lds);
     if (rc != SLFP_OK) return rc;
     // persistent grid: as many workgroups per CU as LDS allows (<= 4), 256 CUs
@@ -411,10 +449,11 @@ static int launch_stream_ks(PwParams& p, hipStream_t stream) {
 }
 
 // W small enough to live in LDS next to nothing else?
-static bool stream_fits(const ConvPlan& plan, int passes) {
-    const size_t w = (size_t)plan.k_pad * plan.n_pad * 2 * (passes == 3 ? 2 : 1);
-    return plan.k_pad <= 256 && w <= 128 * 1024;
+bool pointwise_stream_fits(int64_t k_pad, int64_t n_pad, int passes) {
+    const size_t w = (size_t)k_pad * n_pad * 2 * (passes == 3 ? 2 : 1);
+    return k_pad <= 256 && w <= 128 * 1024;
 }
+static bool stream_fits(const ConvPlan& plan, int passes) { return pointwise_stream_fits(plan.k_pad, plan.n_pad, passes); }
 
 template <int FMT, int PASSES>
 static int launch_pw(PwParams& p, const ConvPlan& plan, hipStream_t stream) {
@@ -429,6 +468,7 @@ static int launch_pw(PwParams& p, const ConvPlan& plan, hipStream_t stream) {
             default: break;
         }
     }
+    if (p.K % 4 || p.N % 4) return fail(SLFP_ERR_UNSUPPORTED, "pointwise: channel counts not a multiple of 4 need the stream kernel");
     if constexpr (PASSES == 3) {
         if (p.N > 128) return launch_tiled<FMT, 3, 1, 4, 4, 4>(p, stream);  // 64 px x 256 ch
         if (p.N > 64) return launch_tiled<FMT, 3, 2, 2, 2, 4>(p, stream);   // 64 px x 128 ch

@@ -66,6 +66,9 @@ int launch_pointwise(const slfp_conv2d_desc& d, const ConvPlan& p, const float* 
 int launch_direct(const slfp_conv2d_desc& d, const ConvPlan& p, const float* x, const float* wq_hwio,
                   const float* bias, const PostOp& post, float* y, hipStream_t stream);
 bool stem_applicable(const slfp_conv2d_desc& d);  // direct family: the small-C_in stem kernel takes it
+// pointwise: does W (padded) fit the LDS-resident stream kernel?  (that kernel also takes even channel
+// counts that are not a multiple of 4, with 8-byte accesses)
+bool pointwise_stream_fits(int64_t k_pad, int64_t n_pad, int passes);
 // dense k x k implicit GEMM on MFMA (conv_dense.hip); wblob = [tap][n_tile][k_step][64][8] fp16;
 // `workspace` (dense_mfma_workspace_bytes) receives the input encoded once to fp16
 bool dense_mfma_applicable(const slfp_conv2d_desc& d, int passes);

@@ -43,7 +43,9 @@ def test_kernel_selection_and_sizes():
     assert name(odd) == "repad+dw3x3_nhwc"                                       # same kernel on channel-padded copies
     assert L.slfp_conv2d_wprep_bytes(ctypes.byref(odd)) == 2304                  # 9*60*4 rounded up to 256
     assert L.slfp_conv2d_workspace_bytes(ctypes.byref(odd)) == 2 * (2 * 16 * 16 * 60 * 4) + 3 * 256
-    assert name(_desc(c_in=58, c_out=58, groups=1, kh=1, kw=1, pad_h=0, pad_w=0)) == "repad+pw_mfma_f16x1"
+    assert name(_desc(c_in=58, c_out=58, groups=1, kh=1, kw=1, pad_h=0, pad_w=0)) == "pw_mfma_f16x1"   # even widths: 8-byte accesses
+    assert name(_desc(c_in=57, c_out=58, groups=1, kh=1, kw=1, pad_h=0, pad_w=0)) == "repad+pw_mfma_f16x1"  # odd: padded copies
+    assert name(_desc(c_in=58, c_out=1026, groups=1, kh=1, kw=1, pad_h=0, pad_w=0)) == "repad+pw_mfma_f16x1"  # W too big for LDS
     assert name(_desc(c_in=58, c_out=58, groups=2)) == "direct_nhwc"             # grouped, not depthwise
     pw = _desc(kh=1, kw=1, pad_h=0, pad_w=0, groups=1, c_in=128, c_out=256)
     assert name(pw) == "pw_mfma_f16x1"                                           # default: one fp16 pass

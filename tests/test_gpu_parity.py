@@ -269,7 +269,10 @@ def _check_against_oracle(lib, dev, N, C, H, O, k, s, p, g, qbits, passes, seed,
     ref = so.conv2d(xs, w.cpu().numpy(), None if b is None else b.cpu().numpy(), s, p, 1, g, Ka, Kw, qbits)
     got = y[idx].permute(0, 3, 1, 2).contiguous().cpu().numpy()
     tol = _tol(kern)
-    assert (kern == "pw_mfma_f16x1") == (k == 1 and g == 1 and qbits == 8 and passes != 3 and C % 4 == 0 and O % 4 == 0)
+    kp, np_ = -(-C // 64) * 64, -(-O // 64) * 64
+    stream_fits = kp <= 256 and kp * np_ * 2 <= 128 * 1024   # even widths need the LDS-resident stream kernel
+    assert (kern == "pw_mfma_f16x1") == (k == 1 and g == 1 and qbits == 8 and passes != 3 and C % 2 == 0 and O % 2 == 0
+                                         and (C % 4 + O % 4 == 0 or (stream_fits and C >= 8)))
     emax, el2 = rel_errors(got, ref)
     assert emax <= tol and el2 <= tol, (kern, (N, C, H, O, k, s), emax, el2)
     return kern, emax, el2
@@ -333,12 +336,18 @@ def test_channel_counts_not_multiple_of_4_vs_oracle(lib, dev):
     layers use 32-wide channel groups with a ragged last group."""
     cases = [(58, 28, 58, 3, 1, 1, 58, False), (58, 29, 58, 3, 2, 1, 58, True), (58, 28, 58, 1, 1, 0, 1, False),
              (24, 28, 58, 1, 1, 0, 1, True), (58, 14, 116, 1, 1, 0, 1, False), (30, 9, 30, 3, 1, 1, 30, True),
-             (24, 30, 24, 3, 2, 1, 24, False), (116, 15, 116, 3, 1, 1, 116, False), (232, 14, 232, 3, 2, 1, 232, True)]
+             (24, 30, 24, 3, 2, 1, 24, False), (116, 15, 116, 3, 1, 1, 116, False), (232, 14, 232, 3, 2, 1, 232, True),
+             (58, 15, 30, 1, 2, 0, 1, True), (27, 10, 58, 1, 1, 0, 1, True), (58, 9, 514, 1, 1, 0, 1, False),
+             (58, 5, 1026, 1, 1, 0, 1, True)]
     for i, (C, H, O, k, s, p, g, bias) in enumerate(cases):
         for qbits, passes in ((8, 0), (8, 3), (7, 0)):
             kern, emax, el2 = _check_against_oracle(lib, dev, 3, C, H, O, k, s, p, g, qbits, passes, seed=700 + i, bias=bias)
-            if C % 4 or O % 4:
-                assert kern.startswith("repad+"), kern
+            if k == 1:
+                planes = 2 if (passes == 3 and qbits == 8) else 1   # W must fit the LDS-resident stream kernel
+                native = C % 2 == 0 and O % 2 == 0 and 64 * (-(-O // 64) * 64) * 2 * planes <= 128 * 1024
+                assert kern.startswith("pw_mfma") if native else kern.startswith("repad+pw_mfma"), kern
+            elif C % 4:
+                assert kern == "repad+dw3x3_nhwc", kern
             else:
                 assert kern == "dw3x3_nhwc", kern
 
