@@ -94,7 +94,8 @@ FAMILY_KERNELS = {"dw3x3_nhwc": ("k_dw3x3",), "stem_nhwc": ("k_stem",), "direct_
                   "pw_mfma_f16x1": ("k_pw_stream", "k_pw_tiled"), "pw_mfma_f16x3": ("k_pw_stream", "k_pw_tiled"),
                   "pw_mfma_f16_exact": ("k_pw_stream", "k_pw_tiled"),
                   "dense_mfma_f16x1": ("k_dense_mfma", "k_dense_encode"), "dense_mfma_f16_exact": ("k_dense_mfma", "k_dense_encode"),
-                  "stem_mfma_f16x1": ("k_stem_mfma", "k_stem_im2row"), "stem_mfma_f16_exact": ("k_stem_mfma", "k_stem_im2row")}
+                  "stem_mfma_f16x1": ("k_stem_mfma", "k_stem_im2row"), "stem_mfma_f16_exact": ("k_stem_mfma", "k_stem_im2row"),
+                  "stem_small_mfma_f16x1": ("k_stem_small",), "stem_small_mfma_f16_exact": ("k_stem_small",)}
 
 
 def pmc_traffic(family):
@@ -333,7 +334,7 @@ def main():
                             "TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1), "launches": v["launches"]}
                         for k, v in fam.items()},
         }
-        if dominant.startswith(("dense_mfma", "stem_mfma")):
+        if dominant.startswith(("dense_mfma", "stem_mfma_")):
             # compute-bound families (VGG-16 / ResNet-50 3x3, large stems): price against the matrix cores.
             # achieved = algorithmic flops (2 * MACs of the layers) / measured time incl. the fp16 encode pre-pass
             tf = dom["flops"] / (dom["ms"] * 1e-3) / 1e12

@@ -58,6 +58,10 @@ static int make_plan_core(const slfp_conv2d_desc* d, ConvPlan* plan) {
         plan->k_pad = ceil_div(d->c_in, 64) * 64;
         plan->n_pad = ceil_div(d->c_out, 64) * 64;
         plan->wprep_bytes = round256((size_t)2 * plan->k_pad * plan->n_pad * sizeof(_Float16));
+    } else if (stem_small_applicable(*d, plan->passes)) {
+        plan->family = kStemSmall;
+        plan->n_pad = stem_small_tiles(*d);  // 16-channel tiles
+        plan->wprep_bytes = round256((size_t)plan->n_pad * 1024);
     } else if (stem_mfma_applicable(*d, plan->passes)) {
         plan->family = kStemMfma;
         int ksub, nt;
@@ -163,6 +167,11 @@ __global__ __launch_bounds__(256) void k_prepare(const float* __restrict__ w, vo
         reinterpret_cast<float*>(prep)[(size_t)(kh * 3 + kw) * ldo + o] = q;  // [9][C (padded)]
     } else if (family == kDirect) {
         reinterpret_cast<float*>(prep)[((size_t)(kh * KW + kw) * Cg + ci) * O + o] = q;  // [KH][KW][Cg][O]
+    } else if (family == kStemSmall) {
+        // one 32-deep k-step: k = (kh*KW + kw)*C_in + ci; A-fragment lane (k/8, o%16), element k%8: conv_stem_small.hip
+        const int k = (kh * KW + kw) * Cg + ci;
+        const size_t at = (((size_t)(o >> 4) * 64) + (size_t)((k >> 3) * 16 + (o & 15))) * 8 + (k & 7);
+        reinterpret_cast<_Float16*>(prep)[at] = (_Float16)(16.0f * q);
     } else if (family == kStemMfma) {
         // K = (kh, run element r = kw*C_in + ci padded to 32*KS): k-step kh*KS + r/32, lane-quarter (r%32)/8;
         // `plane` carries the number of channel tiles: conv_stem_mfma.hip
@@ -194,7 +203,7 @@ int launch_prepare_weights(const slfp_conv2d_desc& d, const ConvPlan& p, const f
                            float* weight_q_oihw, hipStream_t stream) {
     const int Cg = (int)(d.c_in / d.groups);
     const int64_t total = d.c_out * Cg * d.kh * d.kw;
-    if (p.family == kPointwise || p.family == kDenseMfma || p.family == kStemMfma || p.repad) {
+    if (p.family == kPointwise || p.family == kDenseMfma || p.family == kStemMfma || p.family == kStemSmall || p.repad) {
         if (hipMemsetAsync(wprep, 0, p.wprep_bytes, stream) != hipSuccess) return check_launch("hipMemsetAsync(wprep)");
     }
     const int64_t plane = p.family == kStemMfma ? p.n_pad : p.k_pad * p.n_pad;
@@ -221,6 +230,7 @@ static const char* family_name(const ConvPlan& p, const slfp_conv2d_desc& d) {
         case kPointwise: return p.fmt_act == kFmtSfp7 ? "pw_mfma_f16_exact" : (p.passes == 3 ? "pw_mfma_f16x3" : "pw_mfma_f16x1");
         case kDenseMfma: return p.fmt_act == kFmtSfp7 ? "dense_mfma_f16_exact" : "dense_mfma_f16x1";
         case kStemMfma: return p.fmt_act == kFmtSfp7 ? "stem_mfma_f16_exact" : "stem_mfma_f16x1";
+        case kStemSmall: return p.fmt_act == kFmtSfp7 ? "stem_small_mfma_f16_exact" : "stem_small_mfma_f16x1";
         default: return "direct_nhwc";
     }
 }
@@ -358,6 +368,7 @@ int slfp_conv2d_fwd_post(const slfp_conv2d_desc* d, const float* x, const void* 
         case kPointwise: rc = launch_pointwise(*d, p, x_nhwc, wprep, bias, post, y_nhwc, st); break;
         case kDenseMfma: rc = launch_dense_mfma(*d, p, x_nhwc, wprep, bias, post, y_nhwc, ws, st); break;
         case kStemMfma: rc = launch_stem_mfma(*d, p, x_nhwc, wprep, bias, post, y_nhwc, ws, st); break;
+        case kStemSmall: rc = launch_stem_small(*d, p, x_nhwc, wprep, bias, post, y_nhwc, st); break;
         default: rc = launch_direct(*d, p, x_nhwc, reinterpret_cast<const float*>(wprep), bias, post, y_nhwc, st); break;
     }
     if (rc != SLFP_OK) return rc;

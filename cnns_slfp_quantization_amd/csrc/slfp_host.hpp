@@ -33,7 +33,7 @@ inline ScaleDiv make_scale_div(float d, int esh = 0) {
 }
 
 // Kernel families (slfp_conv2d_kernel_name reports them).
-enum KernelFamily { kDw3x3 = 0, kPointwise = 1, kDirect = 2, kDenseMfma = 3, kStemMfma = 4 };
+enum KernelFamily { kDw3x3 = 0, kPointwise = 1, kDirect = 2, kDenseMfma = 3, kStemMfma = 4, kStemSmall = 5 };
 
 struct ConvPlan {
     KernelFamily family;
@@ -85,6 +85,13 @@ void stem_mfma_blob_shape(const slfp_conv2d_desc& d, int* ksub, int* nt);
 size_t stem_mfma_workspace_bytes(const slfp_conv2d_desc& d, int64_t w_out);
 int launch_stem_mfma(const slfp_conv2d_desc& d, const ConvPlan& p, const float* x, const void* wblob,
                      const float* bias, const PostOp& post, float* y, void* workspace, hipStream_t stream);
+
+// 3x3-class image stems whose whole contraction is one MFMA k-step (conv_stem_small.hip);
+// wblob = [o/16][64][8] fp16 with k = (kh*KW + kw)*C_in + c
+bool stem_small_applicable(const slfp_conv2d_desc& d, int passes);
+int stem_small_tiles(const slfp_conv2d_desc& d);
+int launch_stem_small(const slfp_conv2d_desc& d, const ConvPlan& p, const float* x, const void* wblob,
+                      const float* bias, const PostOp& post, float* y, hipStream_t stream);
 
 // XCD-aware block remap (MI355X: 8 XCDs, blocks are dealt round-robin over them, so
 // blocks b and b+8 share an L2).  Maps the hardware block id to a logical id such that

@@ -53,7 +53,12 @@ def test_kernel_selection_and_sizes():
     assert name(pw) == "pw_mfma_f16x3"
     pw.qbits = 7
     assert name(pw) == "pw_mfma_f16_exact"                                       # SFP<3,3> is exact in fp16
-    assert name(_desc(c_in=3, c_out=32, groups=1, stride_h=2, stride_w=2)) == "stem_nhwc"
+    assert name(_desc(c_in=3, c_out=32, groups=1, stride_h=2, stride_w=2)) == "stem_nhwc"   # MobileNetV1 stem: specialised fp32 kernel
+    stem = _desc(c_in=3, c_out=64, groups=1)
+    assert name(stem) == "stem_small_mfma_f16x1"                                 # K = 27: one MFMA k-step
+    assert L.slfp_conv2d_wprep_bytes(ctypes.byref(stem)) == 4 * 1024            # 4 channel tiles x 1 KiB fragment
+    stem.mfma_passes = _lib.MFMA_F16X3
+    assert name(stem) == "stem_nhwc"                                             # float32-equivalent mode: fp32 stem kernel
     dense = _desc(c_in=16, c_out=32, groups=1)
     assert name(dense) == "dense_mfma_f16x1"                                     # dense k x k: implicit GEMM on MFMA
     assert L.slfp_conv2d_wprep_bytes(ctypes.byref(dense)) == 9 * 64 * 32 * 2     # [tap][C_in pad 64][C_out pad 16] fp16
