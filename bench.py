@@ -98,21 +98,34 @@ FAMILY_KERNELS = {"dw3x3_nhwc": ("k_dw3x3",), "stem_nhwc": ("k_stem",), "direct_
                   "stem_small_mfma_f16x1": ("k_stem_small",), "stem_small_mfma_f16_exact": ("k_stem_small",)}
 
 
-def pmc_traffic(family):
-    """HBM bytes per launch of `family` from the newest committed rocprofv3 PMC summary
-    (profiles/*_summary.json: FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, separate --pmc
-    passes of this same bench command).  Returns (bytes_per_launch, tag) or (None, None)."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json")))
-    if not files:
+PREPASS_KERNELS = ("k_dense_encode", "k_stem_im2row")
+
+
+def pmc_traffic(family, net, batch):
+    """HBM bytes per launch of `family` from the newest committed rocprofv3 PMC summary of THIS workload
+    (profiles/index.json lists tag -> net, batch, oldest first; profiles/<tag>_summary.json holds
+    FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE from separate --pmc passes of this same bench
+    command).  Returns (bytes_per_launch, tag) or (None, None)."""
+    try:
+        index = json.load(open(os.path.join(ROOT, "profiles", "index.json")))
+    except OSError:
         return None, None
-    rows = json.load(open(files[-1]))
-    tot = n = 0
-    for r in rows:
-        if r["kernel"].split("<")[0] in FAMILY_KERNELS.get(family, ()) and "hbm_read_MB" in r and "hbm_write_MB" in r:
-            tot += (r["hbm_read_MB"] + r["hbm_write_MB"]) * 1e6 * r["launches"]
-            n += r["launches"]
-    return (int(tot / n), os.path.basename(files[-1]).replace("_summary.json", "")) if n else (None, None)
+    for ent in reversed(index):
+        if ent["net"] != net or ent["batch"] != batch:
+            continue
+        path = os.path.join(ROOT, "profiles", ent["tag"] + "_summary.json")
+        if not os.path.exists(path):
+            continue
+        tot = n = 0
+        launches = None
+        for r in json.load(open(path)):
+            if r["kernel"].split("<")[0] in FAMILY_KERNELS.get(family, ()) and "hbm_read_MB" in r and "hbm_write_MB" in r:
+                tot += (r["hbm_read_MB"] + r["hbm_write_MB"]) * 1e6 * r["launches"]
+                if r["kernel"].split("<")[0] not in PREPASS_KERNELS:
+                    n += r["launches"]   # a pre-pass kernel adds bytes to its layer's launch, not a launch
+        if n:
+            return int(tot / n), ent["tag"]
+    return None, None
 
 
 def whole_net(specs, net, batch, dev, steps):
@@ -327,7 +340,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(dom_gbs, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(dom_gbs / HBM_PEAK_GBS, 4),
                          "frac_of_measured_copy_ceiling": round(dom_gbs / HBM_COPY_GBS, 4),
-                         "traffic": pmc_traffic(dominant)[0], "traffic_profile": pmc_traffic(dominant)[1],
+                         "traffic": pmc_traffic(dominant, args.net, args.batch)[0],
+                         "traffic_profile": pmc_traffic(dominant, args.net, args.batch)[1],
                          "launches_per_step": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
                          "algorithmic_bytes_per_launch": int(dom["bytes"] / dom["launches"])},
             "kernels": {k: {"ms_per_step": round(v["ms"], 4), "GB/s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
