@@ -160,6 +160,7 @@ __global__ __launch_bounds__(kDnThreads, (MT == 4 ? 2 : 4)) void k_dense_mfma(co
     stage_w(0, 0, 0);
     if (n_steps > 1) stage_w(n_taps > 1 ? 1 : 0, n_taps > 1 ? 0 : 1, 1);
     for (int pc = wave; pc < p.x_pieces; pc += 8) stage_x(pc, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     // Per tap: (1) this tap's fragments LDS -> registers; (2) barrier (every wave has read wbuf[wb],
@@ -186,6 +187,11 @@ __global__ __launch_bounds__(kDnThreads, (MT == 4 ? 2 : 4)) void k_dense_mfma(co
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+            // The DMAs issued one tap ago must have landed before the barrier publishes them.  hipcc does
+            // NOT count a global_load_lds issued in the previous loop iteration when it lowers
+            // __syncthreads() here (it emitted lgkmcnt(0) only: rare stale weight fragments at 12 544
+            // workgroups), so the wait is explicit.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             // the weight tile two taps ahead -> the buffer every wave has just finished reading
             int tap2 = tap + 2, chunk2 = chunk;

@@ -393,6 +393,25 @@ def test_full_batch_256_sampled_images(lib, dev, layer):
     _check_against_oracle(lib, dev, 256, C, H, O, k, s, p, g, 8, 1, seed=600 + layer, images=[7, 255])
 
 
+@pytest.mark.parametrize("case", [
+    (64, 224, 64, 3, 1, 1, 16, 7),      # VGG-16 conv1_2: 8-wave BN=64 tiling, 12 544 workgroups
+    (256, 56, 256, 3, 1, 1, 32, 7),     # VGG-16 conv3_x (config 3)
+    (512, 14, 512, 3, 1, 1, 64, 7),     # VGG-16 conv5_x: small images, ragged 16-wide tiles
+    (128, 56, 128, 3, 2, 1, 64, 8),     # ResNet-50 stage-2 downsample 3x3 s2 (config 4)
+    (3, 224, 64, 7, 2, 3, 64, 8),       # ResNet-50 stem: im2row + MFMA
+    (3, 224, 64, 3, 1, 1, 32, 8),       # VGG-16 stem: one-k-step MFMA stem
+    (58, 112, 58, 1, 1, 0, 64, 7),      # ShuffleNetV2 58-channel 1x1 (8-byte accesses), SFP<3,3> (config 5)
+    (58, 112, 58, 3, 1, 1, 64, 7),      # ShuffleNetV2 58-channel depthwise on padded copies
+])
+def test_full_size_layers_of_the_other_configs_sampled_images(lib, dev, case):
+    """BASELINE.json configs 3-5 at their real spatial sizes and a large batch: the MFMA families for
+    compute-bound layers, the re-padded / 8-byte-access paths, checked on sampled images (images are
+    independent units) against the oracle."""
+    C, H, O, k, s, p, N, qbits = case
+    g = C if (k == 3 and C == O == 58) else 1
+    _check_against_oracle(lib, dev, N, C, H, O, k, s, p, g, qbits, 0, seed=900 + C + k, images=[0, N - 1], bias=(C == 64))
+
+
 def test_batch_order_independence(lib, dev):
     """Size-independent property: permuting the images permutes the outputs, bit for bit."""
     Ka, Kw = 0.17, 0.12
