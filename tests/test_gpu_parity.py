@@ -570,7 +570,8 @@ def test_fused_bn_relu_epilogue_matches_stock_modules(dev):
              (C(64, 64, 3, Kw, Ka, 2, 1, groups=64), 64, 21), (C(64, 128, 1, Kw, Ka), 64, 14), (C(256, 512, 1, Kw, Ka), 256, 9),
              (C(16, 32, 3, Kw, Ka, 1, 1), 16, 12), (Cb(16, 32, 3, Kw, Ka, 1, 1), 16, 12),
              # channel counts that are not a multiple of 4: the channel-re-padded launches (bias / BN vectors padded too)
-             (C(58, 58, 3, Kw, Ka, 1, 1, groups=58), 58, 13), (Cb(24, 58, 1, Kw, Ka), 24, 13), (C(3, 64, 7, Kw, Ka, 2, 3), 3, 40)]
+             (C(58, 58, 3, Kw, Ka, 1, 1, groups=58), 58, 13), (Cb(24, 58, 1, Kw, Ka), 24, 13), (C(3, 64, 7, Kw, Ka, 2, 3), 3, 40),
+             (Cb(3, 24, 3, Kw, Ka, 1, 1), 3, 35), (C(57, 30, 1, Kw, Ka), 57, 11)]  # one-k-step MFMA stem; odd width on padded copies
     try:
         for passes in (3, 0):
             cf.options.mfma_passes = passes
