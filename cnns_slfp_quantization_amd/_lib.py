@@ -21,7 +21,7 @@ SYMBOLS = (
     "slfp_encode_f32", "slfp_decode_f32", "slfp_quantize_f32", "slfp_quantize_layerout_f32", "slfp_absmax_f32",
     "slfp_conv2d_out_shape", "slfp_conv2d_kernel_name", "slfp_conv2d_wprep_bytes",
     "slfp_conv2d_prepare_weights", "slfp_conv2d_workspace_bytes", "slfp_conv2d_fwd", "slfp_conv2d_fwd_post",
-    "slfp_linear_workspace_bytes", "slfp_linear_fwd",
+    "slfp_linear_workspace_bytes", "slfp_linear_fwd", "slfp_linear_prepare_weights", "slfp_linear_fwd_prepared",
     "slfp_nchw_to_nhwc_f32", "slfp_nhwc_to_nchw_f32", "slfp_debug_div_mismatches",
 )
 
@@ -78,6 +78,8 @@ def load():
         "slfp_conv2d_fwd_post": (ci, [dp, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp]),
         "slfp_linear_workspace_bytes": (sz, [i64, i64, i64]),
         "slfp_linear_fwd": (ci, [vp, vp, vp, vp, i64, i64, i64, cf, cf, ci, ci, vp, vp]),
+        "slfp_linear_prepare_weights": (ci, [vp, vp, i64, i64, cf, ci, ci, vp]),
+        "slfp_linear_fwd_prepared": (ci, [vp, vp, vp, vp, i64, i64, i64, cf, cf, ci, ci, vp]),
         "slfp_nchw_to_nhwc_f32": (ci, [vp, vp, i64, i64, i64, i64, vp]),
         "slfp_nhwc_to_nchw_f32": (ci, [vp, vp, i64, i64, i64, i64, vp]),
         "slfp_debug_div_mismatches": (ci, [cf, vp, vp]),

@@ -387,31 +387,55 @@ size_t slfp_linear_workspace_bytes(int64_t batch, int64_t in_f, int64_t out_f) {
     return p.wprep_bytes;
 }
 
-int slfp_linear_fwd(const float* x, const float* w, const float* bias, float* y, int64_t batch, int64_t in_f,
-                    int64_t out_f, float ka, float kw_scale, int qbits, int mfma_passes, void* workspace,
-                    void* stream) {
+static void linear_desc(slfp_conv2d_desc* d, int64_t batch, int64_t in_f, int64_t out_f, float ka, float kw_scale,
+                        int qbits, int mfma_passes) {
     // Linear_Q.forward (utils/conv2d_func.py:60-65) = a 1x1 convolution over `batch` pixels,
     // except that the reference divides the bias by Kw first and rescales by Kw first.
+    memset(d, 0, sizeof(*d));
+    d->n = batch; d->c_in = in_f; d->h = 1; d->w = 1; d->c_out = out_f; d->kh = 1; d->kw = 1;
+    d->stride_h = d->stride_w = d->dil_h = d->dil_w = d->groups = 1;
+    d->x_layout = d->y_layout = SLFP_LAYOUT_NHWC; d->qbits = qbits; d->ka = ka; d->kw_scale = kw_scale;
+    d->mfma_passes = mfma_passes;
+}
+
+int slfp_linear_prepare_weights(const float* w, void* wprep, int64_t in_f, int64_t out_f, float kw_scale, int qbits,
+                                int mfma_passes, void* stream) {
     slfp_conv2d_desc d;
-    memset(&d, 0, sizeof(d));
-    d.n = batch; d.c_in = in_f; d.h = 1; d.w = 1; d.c_out = out_f; d.kh = 1; d.kw = 1;
-    d.stride_h = d.stride_w = d.dil_h = d.dil_w = d.groups = 1;
-    d.x_layout = d.y_layout = SLFP_LAYOUT_NHWC; d.qbits = qbits; d.ka = ka; d.kw_scale = kw_scale;
-    d.mfma_passes = mfma_passes;
+    linear_desc(&d, 1, in_f, out_f, 1.0f, kw_scale, qbits, mfma_passes);
     ConvPlan p;
-    int rc = make_plan_core(&d, &p);  // no channel re-padding here: odd feature counts take the direct kernel
+    const int rc = make_plan_core(&d, &p);  // no channel re-padding here: odd feature counts take the direct kernel
     if (rc != SLFP_OK) return rc;
-    if (!x || !w || !y || !workspace) return fail(SLFP_ERR_BAD_ARG, "slfp_linear_fwd: null pointer");
-    if (!aligned16(x) || !aligned16(y) || !aligned16(workspace) || (bias && !aligned16(bias)))
+    if (!w || !wprep) return fail(SLFP_ERR_BAD_ARG, "slfp_linear_prepare_weights: null pointer");
+    if (!aligned16(wprep)) return fail(SLFP_ERR_ALIGNMENT, "slfp_linear_prepare_weights: wprep must be 16-byte aligned");
+    return launch_prepare_weights(d, p, w, wprep, nullptr, as_stream(stream));
+}
+
+int slfp_linear_fwd_prepared(const float* x, const void* wprep, const float* bias, float* y, int64_t batch, int64_t in_f,
+                             int64_t out_f, float ka, float kw_scale, int qbits, int mfma_passes, void* stream) {
+    slfp_conv2d_desc d;
+    linear_desc(&d, batch, in_f, out_f, ka, kw_scale, qbits, mfma_passes);
+    ConvPlan p;
+    const int rc = make_plan_core(&d, &p);
+    if (rc != SLFP_OK) return rc;
+    if (!x || !wprep || !y) return fail(SLFP_ERR_BAD_ARG, "slfp_linear_fwd: null pointer");
+    if (!aligned16(x) || !aligned16(y) || !aligned16(wprep) || (bias && !aligned16(bias)))
         return fail(SLFP_ERR_ALIGNMENT, "slfp_linear_fwd: pointers must be 16-byte aligned");
-    hipStream_t st = as_stream(stream);
-    rc = launch_prepare_weights(d, p, w, workspace, nullptr, st);  // the reference re-quantizes per call too
-    if (rc != SLFP_OK) return rc;
     p.s1 = kw_scale;
     p.s2 = ka;
     const PostOp none{nullptr, nullptr, 0};
-    if (p.family == kPointwise) return launch_pointwise(d, p, x, workspace, bias, none, y, st);
-    return launch_direct(d, p, x, reinterpret_cast<const float*>(workspace), bias, none, y, st);
+    hipStream_t st = as_stream(stream);
+    if (p.family == kPointwise) return launch_pointwise(d, p, x, wprep, bias, none, y, st);
+    return launch_direct(d, p, x, reinterpret_cast<const float*>(wprep), bias, none, y, st);
+}
+
+int slfp_linear_fwd(const float* x, const float* w, const float* bias, float* y, int64_t batch, int64_t in_f,
+                    int64_t out_f, float ka, float kw_scale, int qbits, int mfma_passes, void* workspace,
+                    void* stream) {
+    if (!workspace) return fail(SLFP_ERR_BAD_ARG, "slfp_linear_fwd: null pointer");
+    // the reference re-quantizes the weights on every call; so does this entry point
+    const int rc = slfp_linear_prepare_weights(w, workspace, in_f, out_f, kw_scale, qbits, mfma_passes, stream);
+    if (rc != SLFP_OK) return rc;
+    return slfp_linear_fwd_prepared(x, workspace, bias, y, batch, in_f, out_f, ka, kw_scale, qbits, mfma_passes, stream);
 }
 
 }  // extern "C"

@@ -140,6 +140,16 @@ size_t slfp_linear_workspace_bytes(int64_t batch, int64_t in_f, int64_t out_f);
 int slfp_linear_fwd(const float* x, const float* w, const float* bias, float* y, int64_t batch,
                     int64_t in_f, int64_t out_f, float ka, float kw_scale, int qbits, int mfma_passes,
                     void* workspace, void* stream);
+/* The same with the weights quantized ONCE (inference: AlexNet's 9216x4096 and VGG-16's 25088x4096
+ * fully-connected layers would otherwise be re-encoded on every forward):
+ * slfp_linear_prepare_weights fills `wprep` (slfp_linear_workspace_bytes(1, in_f, out_f) bytes; the
+ * blob depends on kw_scale, qbits and mfma_passes, not on the batch), slfp_linear_fwd_prepared
+ * consumes it.  slfp_linear_fwd == prepare + fwd_prepared on the caller's workspace. */
+int slfp_linear_prepare_weights(const float* w, void* wprep, int64_t in_f, int64_t out_f, float kw_scale,
+                                int qbits, int mfma_passes, void* stream);
+int slfp_linear_fwd_prepared(const float* x, const void* wprep, const float* bias, float* y, int64_t batch,
+                             int64_t in_f, int64_t out_f, float ka, float kw_scale, int qbits,
+                             int mfma_passes, void* stream);
 
 /* ---- self-check ------------------------------------------------------------------------
  * The kernels compute x / scale_div with an FMA correction chain on a host-computed

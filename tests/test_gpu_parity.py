@@ -197,7 +197,7 @@ def test_conv_golden_cases(lib, dev, conv_golden, layout, passes):
         cf.options.mfma_passes = 0
 
 
-def test_linear_golden(dev, conv_golden):
+def test_linear_golden(lib, dev, conv_golden):
     import utils.conv2d_func as cf
     Ka, Kw = [np.float64(v) for v in conv_golden["linear_scales"]]
     try:
@@ -210,6 +210,36 @@ def test_linear_golden(dev, conv_golden):
                 y = m(torch.from_numpy(conv_golden["linear_x"]).to(dev))
             emax, el2 = rel_errors(y.cpu().numpy(), conv_golden[f"linear_q{q}_y"])
             assert emax <= tol and el2 <= tol, (q, passes, emax, el2)
+            # the quantized weights are cached per weight version: same result on the second call, a new blob
+            # after an in-place update, and the one-shot C entry point (prepare + forward) agrees bit for bit
+            with torch.no_grad():
+                blob0 = m._lin_prep[1]
+                y2 = m(torch.from_numpy(conv_golden["linear_x"]).to(dev))
+                assert torch.equal(y, y2) and m._lin_prep[1] is blob0
+                m.weight.mul_(0.5)
+                y3 = m(torch.from_numpy(conv_golden["linear_x"]).to(dev))
+                assert m._lin_prep[1] is not blob0 and not torch.equal(y3, y)
+                ref3 = tp.linear_q(torch.from_numpy(conv_golden["linear_x"]).to(dev), m.weight, m.bias, Ka, Kw, q)
+                assert rel_errors(y3.cpu().numpy(), ref3.cpu().numpy())[0] <= tol
+        # larger, classifier-like shape with an odd batch, through the C ABI both ways
+        _lib = lib
+        L = _lib.load()
+        g = torch.Generator(device="cpu").manual_seed(11)
+        x = (torch.randn((37, 512), generator=g).abs() * 0.7).to(dev)
+        w = (torch.randn((1000, 512), generator=g) * 0.3).to(dev)
+        b = torch.randn(1000, generator=g).to(dev)
+        ka, kw = float(np.float32(0.21)), float(np.float32(0.05))
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        ws = torch.empty(L.slfp_linear_workspace_bytes(37, 512, 1000), dtype=torch.uint8, device=dev)
+        y_once = torch.empty((37, 1000), device=dev)
+        y_prep = torch.empty((37, 1000), device=dev)
+        _lib.check(L.slfp_linear_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y_once.data_ptr(), 37, 512, 1000, ka, kw, 8, 1, ws.data_ptr(), st))
+        blob = torch.empty(L.slfp_linear_workspace_bytes(1, 512, 1000), dtype=torch.uint8, device=dev)
+        _lib.check(L.slfp_linear_prepare_weights(w.data_ptr(), blob.data_ptr(), 512, 1000, kw, 8, 1, st))
+        _lib.check(L.slfp_linear_fwd_prepared(x.data_ptr(), blob.data_ptr(), b.data_ptr(), y_prep.data_ptr(), 37, 512, 1000, ka, kw, 8, 1, st))
+        assert torch.equal(y_once, y_prep)
+        ref = so.linear(x.cpu().numpy(), w.cpu().numpy(), b.cpu().numpy(), ka, kw, 8)
+        assert rel_errors(y_prep.cpu().numpy(), ref)[0] <= TOL_F16X1
     finally:
         cf.options.mfma_passes = 0
 
