@@ -166,6 +166,31 @@ def whole_net(specs, net, batch, dev, steps):
                 model(x)
             torch.cuda.synchronize()
             out[tag] = round(batch * steps / (time.perf_counter() - t0), 1)
+        # the fused net replayed as ONE hipGraph (all launches go to the capture stream through the C ABI):
+        # removes the per-layer Python/launch latency and the inter-kernel gaps
+        try:
+            static_x = x.clone()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    model(static_x)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_y = model(static_x)
+            graph.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                graph.replay()
+            torch.cuda.synchronize()
+            out["fused_bn_relu_hipgraph"] = round(batch * steps / (time.perf_counter() - t0), 1)
+            ref_y = model(static_x)
+            out["hipgraph_matches_eager"] = bool(torch.equal(ref_y, static_y))
+        except Exception as e:  # graph capture is an optimisation of the secondary number only
+            out["fused_bn_relu_hipgraph"] = None
+            out["hipgraph_error"] = str(e)[:200]
     out["unit"] = "images/sec"
     out["note"] = "whole MobileNetV1-224 incl. BN/ReLU/pool/fc through the drop-in modules, 1 GPU, batch %d" % batch
     return out
