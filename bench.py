@@ -40,7 +40,7 @@ MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak (same guide; never th
 class Layer:
     """One Conv2d_Q layer of the workload, bound to device buffers."""
 
-    def __init__(self, L, spec, batch, dev, passes, gen, qbits=8):
+    def __init__(self, L, spec, batch, dev, passes, gen, qbits=8, post=False):
         self.spec = spec
         self.batch = batch
         s = spec
@@ -64,6 +64,9 @@ class Layer:
         ws = L.slfp_conv2d_workspace_bytes(ctypes.byref(self.desc))  # dense k x k layers: input encoded once to fp16
         self.ws = torch.empty(ws, dtype=torch.uint8, device=dev) if ws else None
         self.bytes = spec.algorithmic_bytes(batch)
+        # --post: the fused eval-BN + ReLU epilogue (slfp_conv2d_fwd_post) on every layer, to price it
+        self.post = (torch.rand(s.c_out, generator=gen, device=dev) + 0.5,
+                     torch.randn(s.c_out, generator=gen, device=dev) * 0.1) if post else None
 
     def set_passes(self, L, stream, passes):
         """Switch the MFMA precision mode.  The prepared blob is specific to the kernel family the
@@ -83,6 +86,14 @@ class Layer:
                                                  None, stream))
 
     def run(self, L, stream):
+        if self.post is not None:
+            rc = L.slfp_conv2d_fwd_post(ctypes.byref(self.desc), self.x.data_ptr(), self.blob.data_ptr(),
+                                        self.bias.data_ptr() if self.bias is not None else None,
+                                        self.post[0].data_ptr(), self.post[1].data_ptr(), 1, self.y.data_ptr(),
+                                        None, self.ws.data_ptr() if self.ws is not None else None, stream)
+            if rc != 0:
+                _lib.check(rc)
+            return
         rc = L.slfp_conv2d_fwd(ctypes.byref(self.desc), self.x.data_ptr(), self.blob.data_ptr(),
                                self.bias.data_ptr() if self.bias is not None else None, self.y.data_ptr(),
                                None, self.ws.data_ptr() if self.ws is not None else None, stream)
@@ -241,6 +252,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
     ap.add_argument("--passes", type=int, default=0, choices=[0, 1, 3], help="pointwise MFMA precision (0 = library default)")
     ap.add_argument("--qbits", type=int, default=8, choices=[8, 7], help="8 = SLFP<3,4> (headline), 7 = SFP<3,3> (BASELINE config 5)")
+    ap.add_argument("--post", action="store_true", help="run every layer with the fused BN+ReLU epilogue (secondary measurement)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-whole-net", action="store_true")
     ap.add_argument("--cpu-sample-batch", type=int, default=16)
@@ -263,7 +275,7 @@ def main():
 
     specs = layer_specs.conv_layers(args.net)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    layers = [Layer(L, s, args.batch, dev, args.passes, gen, args.qbits) for s in specs]
+    layers = [Layer(L, s, args.batch, dev, args.passes, gen, args.qbits, args.post) for s in specs]
     stream = torch.cuda.current_stream().cuda_stream
 
     # quantize the weights ONCE on rank 0 and broadcast the prepared blobs as one bucket

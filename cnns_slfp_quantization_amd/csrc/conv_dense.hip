@@ -231,6 +231,7 @@ __global__ __launch_bounds__(kDnThreads, (MT == 4 ? 2 : 4)) void k_dense_mfma(co
             bq = make_float4(256.f * ((bb.x / p.s1) / p.s2), 256.f * ((bb.y / p.s1) / p.s2),
                              256.f * ((bb.z / p.s1) / p.s2), 256.f * ((bb.w / p.s1) / p.s2));
         }
+        const PostVec pv = post_load(p.post, ch);
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int goh = th * TH + wm * MT + i;
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(kDnThreads, (MT == 4 ? 2 : 4)) void k_dense_mfma(co
             r.y = ((acc[i][j][1] + bq.y) * p.s1x) * p.s2;
             r.z = ((acc[i][j][2] + bq.z) * p.s1x) * p.s2;
             r.w = ((acc[i][j][3] + bq.w) * p.s1x) * p.s2;
-            *reinterpret_cast<float4*>(p.y + (((size_t)n * p.Ho + goh) * p.Wo + gow) * p.O + ch) = post_apply(r, p.post, ch);
+            *reinterpret_cast<float4*>(p.y + (((size_t)n * p.Ho + goh) * p.Wo + gow) * p.O + ch) = post_apply_v(r, p.post, pv);
         }
     }
 }

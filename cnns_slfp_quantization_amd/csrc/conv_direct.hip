@@ -244,6 +244,7 @@ __global__ __launch_bounds__(256) void k_stem(const float* __restrict__ x, const
     }
     const int gow = tw * kStemTW + col;
     if (gow >= p.Wo) return;
+    const PostVec pv = post_load(p.post, c4 * 4);  // once per thread, not per stored row
 #pragma unroll
     for (int q = 0; q < PMAX; ++q) {
         const int goh = th * kStemTH + row0 + q;
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(256) void k_stem(const float* __restrict__ x, const
             r.y = ((acc[q].y + bq.y) * p.s1) * p.s2;
             r.z = ((acc[q].z + bq.z) * p.s1) * p.s2;
             r.w = ((acc[q].w + bq.w) * p.s1) * p.s2;
-            *reinterpret_cast<float4*>(y + (((size_t)n * p.Ho + goh) * p.Wo + gow) * p.O + c4 * 4) = post_apply(r, p.post, c4 * 4);
+            *reinterpret_cast<float4*>(y + (((size_t)n * p.Ho + goh) * p.Wo + gow) * p.O + c4 * 4) = post_apply_v(r, p.post, pv);
         }
     }
 }
@@ -340,6 +341,7 @@ __global__ __launch_bounds__(256) void k_stem_fixed(const float* __restrict__ x,
     const int gow = tw * kStemTW + col;
     if (gow >= p.Wo) return;
     float* yb = y + (((size_t)n * p.Ho + th * kStemTH + row0) * p.Wo + gow) * O + c4 * 4;
+    const PostVec pv = post_load(p.post, c4 * 4);  // once per thread, not per stored row
 #pragma unroll
     for (int q = 0; q < P; ++q) {
         if (th * kStemTH + row0 + q < p.Ho) {
@@ -348,7 +350,7 @@ __global__ __launch_bounds__(256) void k_stem_fixed(const float* __restrict__ x,
             r.y = ((acc[q].y + bq.y) * p.s1) * p.s2;
             r.z = ((acc[q].z + bq.z) * p.s1) * p.s2;
             r.w = ((acc[q].w + bq.w) * p.s1) * p.s2;
-            *reinterpret_cast<float4*>(yb + (uint32_t)(q * p.Wo * O)) = post_apply(r, p.post, c4 * 4);
+            *reinterpret_cast<float4*>(yb + (uint32_t)(q * p.Wo * O)) = post_apply_v(r, p.post, pv);
         }
     }
 }

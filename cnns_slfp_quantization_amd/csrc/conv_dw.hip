@@ -83,6 +83,8 @@ __global__ __launch_bounds__(kDwThreads) void k_dw3x3(const float* __restrict__ 
 #pragma unroll
         for (int t = 0; t < 9; ++t) wt[t] = zero4;
     }
+    // fused BN/ReLU vectors of this thread's 4 channels: loaded once, not per output
+    const PostVec pv = c_live ? post_load(p.post, my_c) : PostVec{zero4, zero4};
     __syncthreads();
 
     // ---------------- LOAD + ENCODE phase ----------------
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(kDwThreads) void k_dw3x3(const float* __restrict__ 
                 r.y = (acc.y * p.ka) * p.kw;
                 r.z = (acc.z * p.ka) * p.kw;
                 r.w = (acc.w * p.ka) * p.kw;
-                *reinterpret_cast<float4*>(yn + (uint32_t)yoff) = post_apply(r, p.post, my_c);
+                *reinterpret_cast<float4*>(yn + (uint32_t)yoff) = post_apply_v(r, p.post, pv);
             }
             oh += p.out_step_h; goh += p.out_step_h;
             ow += p.out_step_w; gow += p.out_step_w;

@@ -115,15 +115,6 @@ __device__ __forceinline__ float4 bias_q256(const PwParams& p, int n) {
                        256.f * ((bb.z / p.s1) / p.s2), 256.f * ((bb.w / p.s1) / p.s2));
 }
 
-// 4 consecutive per-channel values starting at channel n (even) of an N-long vector (N even), read as
-// two 8-byte halves; channels >= N come back as 0.  For channel counts that are not a multiple of 4.
-__device__ __forceinline__ float4 load4_even(const float* v, int n, int N) {
-    float2 a = make_float2(0.f, 0.f), b = a;
-    if (n < N) a = *reinterpret_cast<const float2*>(v + n);
-    if (n + 2 < N) b = *reinterpret_cast<const float2*>(v + n + 2);
-    return make_float4(a.x, a.y, b.x, b.y);
-}
-
 // ======================================================================================
 // k_pw_stream: W resident in LDS, X straight into MFMA fragments, 16-pixel work units.
 // ======================================================================================
@@ -145,6 +136,17 @@ __global__ __launch_bounds__(kStreamThreads) void k_pw_stream(const PwParams p) 
     for (int i = threadIdx.x; i < wfrags * 64; i += kStreamThreads) {
         reinterpret_cast<half8*>(wl_hi)[i] = reinterpret_cast<const half8*>(p.whi)[i];
         if constexpr (PASSES == 3) reinterpret_cast<half8*>(wl_lo)[i] = reinterpret_cast<const half8*>(p.wlo)[i];
+    }
+    // per-channel epilogue vectors -> LDS once per workgroup: [256 * bias/s1/s2 | post scale | post shift],
+    // padded to the blob's channel count.  Read from global inside the sweep, the loads (and the 12 bias
+    // divisions) sit on the critical path of every 16-byte store: +12-38 % on these layers (bench.py --post).
+    float* ep = reinterpret_cast<float*>(smem + 64 + (size_t)(PASSES == 3 ? 2 : 1) * wfrags * 1024);
+    const int n_pad = p.n_tiles * 16;
+    for (int i = threadIdx.x; i < n_pad; i += kStreamThreads) {
+        const bool in = i < p.N;
+        ep[i] = (p.bias && in) ? 256.f * ((p.bias[i] / p.s1) / p.s2) : 0.f;
+        ep[n_pad + i] = (p.post.scale && in) ? p.post.scale[i] : 1.f;
+        ep[2 * n_pad + i] = (p.post.scale && in) ? p.post.shift[i] : 0.f;
     }
     __syncthreads();
 
@@ -216,25 +218,20 @@ __global__ __launch_bounds__(kStreamThreads) void k_pw_stream(const PwParams p) 
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[ks], acc, 0, 0, 0);
             }
             const int n = j * 16 + kq * 4;
+            const float4 bq = *reinterpret_cast<const float4*>(ep + n);
+            float4 r = epilogue(acc, bq, p.s1x, p.s2);
+            if (p.post.scale) {
+                const float4 sc = *reinterpret_cast<const float4*>(ep + n_pad + n);
+                const float4 sh = *reinterpret_cast<const float4*>(ep + 2 * n_pad + n);
+                r.x = __builtin_fmaf(r.x, sc.x, sh.x); r.y = __builtin_fmaf(r.y, sc.y, sh.y);
+                r.z = __builtin_fmaf(r.z, sc.z, sh.z); r.w = __builtin_fmaf(r.w, sc.w, sh.w);
+            }
+            if (p.post.relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
             if constexpr (A8) {
-                float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p.bias) {
-                    const float4 bb = load4_even(p.bias, n, p.N);
-                    bq = make_float4(256.f * ((bb.x / p.s1) / p.s2), 256.f * ((bb.y / p.s1) / p.s2),
-                                     256.f * ((bb.z / p.s1) / p.s2), 256.f * ((bb.w / p.s1) / p.s2));
-                }
-                float4 r = epilogue(acc, bq, p.s1x, p.s2);
-                if (p.post.scale) {
-                    const float4 sc = load4_even(p.post.scale, n, p.N), sh = load4_even(p.post.shift, n, p.N);
-                    r.x = __builtin_fmaf(r.x, sc.x, sh.x); r.y = __builtin_fmaf(r.y, sc.y, sh.y);
-                    r.z = __builtin_fmaf(r.z, sc.z, sh.z); r.w = __builtin_fmaf(r.w, sc.w, sh.w);
-                }
-                if (p.post.relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
                 if (live && n < p.N) *reinterpret_cast<float2*>(yr + j * 16) = make_float2(r.x, r.y);
                 if (live && n + 2 < p.N) *reinterpret_cast<float2*>(yr + j * 16 + 2) = make_float2(r.z, r.w);
             } else {
-                if (live && n < p.N)
-                    *reinterpret_cast<float4*>(yr + j * 16) = post_apply(epilogue(acc, bias_q256(p, n), p.s1x, p.s2), p.post, n);
+                if (live && n < p.N) *reinterpret_cast<float4*>(yr + j * 16) = r;
             }
         }
     }
@@ -389,11 +386,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 4) void k_pw_til
         const int n = (ntile0 + j) * 16 + kq * 4;
         if (n >= p.N) continue;
         const float4 bq = bias_q256(p, n);
+        const PostVec pv = post_load(p.post, n);
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int64_t m = m0 + (wm * MT + i) * 16 + col;
             if (m >= p.M) continue;
-            *reinterpret_cast<float4*>(p.y + (size_t)m * p.N + n) = post_apply(epilogue(acc[i][j], bq, p.s1x, p.s2), p.post, n);
+            *reinterpret_cast<float4*>(p.y + (size_t)m * p.N + n) = post_apply_v(epilogue(acc[i][j], bq, p.s1x, p.s2), p.post, pv);
         }
     }
 }
@@ -432,7 +430,7 @@ static int launch_tiled(PwParams& p, hipStream_t stream) {
 
 template <int FMT, int PASSES, int KS>
 static int launch_stream_ks(PwParams& p, hipStream_t stream) {
-    const size_t lds = 64 + (size_t)(PASSES == 3 ? 2 : 1) * p.n_tiles * p.KS * 1024;
+    const size_t lds = 64 + (size_t)(PASSES == 3 ? 2 : 1) * p.n_tiles * p.KS * 1024 + (size_t)3 * p.n_tiles * 16 * sizeof(float);
     auto fn = (p.K % 4 || p.N % 4) ? k_pw_stream<FMT, PASSES, KS, false, true>
               : (p.K % 32 == 0)    ? k_pw_stream<FMT, PASSES, KS, true> : k_pw_stream<FMT, PASSES, KS, false>;
     int rc = set_lds_limit(reinterpret_cast<const void*>(fn), lds);

@@ -97,6 +97,23 @@ __global__ __launch_bounds__(kSmThreads, 2) void k_stem_mfma(const StemMfmaParam
     const int64_t chunk = (p.units + gridDim.x - 1) / gridDim.x;
     const int64_t u_begin = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * chunk;
     const int64_t u_end = u_begin + chunk < p.units ? u_begin + chunk : p.units;
+    // this lane's channels are the same for every unit: bias / BN vectors once, not per store
+    float4 bqv[NT];
+    PostVec pvv[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int ch = j * 16 + kq * 4;
+        bqv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        pvv[j] = PostVec{make_float4(1.f, 1.f, 1.f, 1.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+        if (ch < p.O) {
+            if (p.bias) {
+                const float4 bb = *reinterpret_cast<const float4*>(p.bias + ch);
+                bqv[j] = make_float4(256.f * ((bb.x / p.s1) / p.s2), 256.f * ((bb.y / p.s1) / p.s2),
+                                     256.f * ((bb.z / p.s1) / p.s2), 256.f * ((bb.w / p.s1) / p.s2));
+            }
+            pvv[j] = post_load(p.post, ch);
+        }
+    }
     for (int64_t u = u_begin + wave; u < u_end; u += kSmThreads / 64) {
         const int seg = (int)(u % p.segs);
         const int64_t t = u / p.segs;
@@ -138,18 +155,13 @@ __global__ __launch_bounds__(kSmThreads, 2) void k_stem_mfma(const StemMfmaParam
             for (int j = 0; j < NT; ++j) {
                 const int ch = j * 16 + kq * 4;
                 if (ch >= p.O) continue;
-                float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p.bias) {
-                    const float4 bb = *reinterpret_cast<const float4*>(p.bias + ch);
-                    bq = make_float4(256.f * ((bb.x / p.s1) / p.s2), 256.f * ((bb.y / p.s1) / p.s2),
-                                     256.f * ((bb.z / p.s1) / p.s2), 256.f * ((bb.w / p.s1) / p.s2));
-                }
+                const float4 bq = bqv[j];
                 float4 r;
                 r.x = ((acc[j][0] + bq.x) * p.s1x) * p.s2;
                 r.y = ((acc[j][1] + bq.y) * p.s1x) * p.s2;
                 r.z = ((acc[j][2] + bq.z) * p.s1x) * p.s2;
                 r.w = ((acc[j][3] + bq.w) * p.s1x) * p.s2;
-                *reinterpret_cast<float4*>(yp + ch) = post_apply(r, p.post, ch);
+                *reinterpret_cast<float4*>(yp + ch) = post_apply_v(r, p.post, pvv[j]);
             }
         }
     }

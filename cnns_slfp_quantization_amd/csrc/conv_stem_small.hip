@@ -103,6 +103,23 @@ __global__ __launch_bounds__(kSsThreads) void k_stem_small(const StemSmallParams
     }
     __syncthreads();
 
+    // this lane's channels are the same for every unit: bias / BN vectors once, not per store
+    float4 bqv[NT];
+    PostVec pvv[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int ch = j * 16 + kq * 4;
+        bqv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        pvv[j] = PostVec{make_float4(1.f, 1.f, 1.f, 1.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+        if (ch < p.O) {
+            if (p.bias) {
+                const float4 bb = *reinterpret_cast<const float4*>(p.bias + ch);
+                bqv[j] = make_float4(256.f * ((bb.x / p.s1) / p.s2), 256.f * ((bb.y / p.s1) / p.s2),
+                                     256.f * ((bb.z / p.s1) / p.s2), 256.f * ((bb.w / p.s1) / p.s2));
+            }
+            pvv[j] = post_load(p.post, ch);
+        }
+    }
     // ---- units: (output row of the tile, 16-pixel segment)
     for (int u = wave; u < kSsTH * (kSsTW / 16); u += kSsThreads / 64) {
         const int orow = u >> 1, seg = u & 1;
@@ -121,18 +138,13 @@ __global__ __launch_bounds__(kSsThreads) void k_stem_small(const StemSmallParams
             for (int j = 0; j < NT; ++j) {
                 const int ch = j * 16 + kq * 4;
                 if (ch >= p.O) continue;
-                float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p.bias) {
-                    const float4 bb = *reinterpret_cast<const float4*>(p.bias + ch);
-                    bq = make_float4(256.f * ((bb.x / p.s1) / p.s2), 256.f * ((bb.y / p.s1) / p.s2),
-                                     256.f * ((bb.z / p.s1) / p.s2), 256.f * ((bb.w / p.s1) / p.s2));
-                }
+                const float4 bq = bqv[j];
                 float4 r;
                 r.x = ((acc[j][0] + bq.x) * p.s1x) * p.s2;
                 r.y = ((acc[j][1] + bq.y) * p.s1x) * p.s2;
                 r.z = ((acc[j][2] + bq.z) * p.s1x) * p.s2;
                 r.w = ((acc[j][3] + bq.w) * p.s1x) * p.s2;
-                *reinterpret_cast<float4*>(yp + ch) = post_apply(r, p.post, ch);
+                *reinterpret_cast<float4*>(yp + ch) = post_apply_v(r, p.post, pvv[j]);
             }
         }
     }
