@@ -232,7 +232,10 @@ def cpu_baseline(specs, sample_batch, iters):
             for s, x, w, b in data:
                 tp.conv2d_q(x, w, b, s.stride, s.pad, 1, s.groups, np.float64(s.Ka), np.float64(s.Kw), 8)
 
-    one_pass()  # warm-up
+    t0 = time.perf_counter()
+    one_pass()  # warm-up, also sizes the sample: about 10 s of CPU work
+    t_pass = time.perf_counter() - t0
+    iters = max(iters, min(40, int(10.0 / max(t_pass, 1e-3))))
     t0 = time.perf_counter()
     for _ in range(iters):
         one_pass()
