@@ -442,6 +442,26 @@ def test_full_size_layers_of_the_other_configs_sampled_images(lib, dev, case):
     _check_against_oracle(lib, dev, N, C, H, O, k, s, p, g, qbits, 0, seed=900 + C + k, images=[0, N - 1], bias=(C == 64))
 
 
+def test_run_to_run_determinism_at_full_size(lib, dev):
+    """No atomics and no split-K anywhere on the path: the same launch must reproduce itself bit for bit.
+    A race (a fragment read before its DMA landed, an LDS tile overwritten early) shows up here as a
+    mismatch between repeats even when each run is within tolerance of the oracle."""
+    Ka, Kw = 0.17, 0.12
+    g = torch.Generator(device=dev).manual_seed(9)
+    # (N, C, H, O, k, s, p, groups, qbits): one big launch per kernel family / tiling
+    cases = [(64, 64, 112, 64, 3, 2, 1, 64, 8), (64, 32, 112, 64, 1, 1, 0, 1, 8), (64, 512, 14, 512, 1, 1, 0, 1, 8),
+             (64, 3, 224, 32, 3, 2, 1, 1, 8), (16, 64, 224, 64, 3, 1, 1, 1, 7), (32, 256, 56, 256, 3, 1, 1, 1, 8),
+             (64, 512, 14, 512, 3, 1, 1, 1, 8), (64, 128, 56, 128, 3, 2, 1, 1, 8), (32, 3, 224, 64, 7, 2, 3, 1, 8),
+             (32, 3, 224, 64, 3, 1, 1, 1, 8), (64, 58, 56, 58, 1, 1, 0, 1, 7), (64, 58, 56, 58, 3, 1, 1, 58, 7)]
+    for (N, C, H, O, k, s, p, grp, q) in cases:
+        x = torch.relu(torch.randn((N, H, H, C), generator=g, device=dev))
+        w = torch.randn((O, C // grp, k, k), generator=g, device=dev) * 0.3
+        y0, kern = _raw_conv(lib, dev, x, w, None, s, p, grp, Ka, Kw, q)
+        for _ in range(3):
+            y1, _ = _raw_conv(lib, dev, x, w, None, s, p, grp, Ka, Kw, q)
+            assert torch.equal(y0, y1), (kern, (N, C, H, O, k, s))
+
+
 def test_batch_order_independence(lib, dev):
     """Size-independent property: permuting the images permutes the outputs, bit for bit."""
     Ka, Kw = 0.17, 0.12
