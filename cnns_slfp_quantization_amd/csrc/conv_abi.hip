@@ -73,7 +73,8 @@ static int make_plan_core(const slfp_conv2d_desc* d, ConvPlan* plan) {
         plan->family = kDenseMfma;
         plan->k_pad = ceil_div(d->c_in, 64) * 64;
         plan->n_pad = ceil_div(d->c_out, 16) * 16;
-        plan->wprep_bytes = round256((size_t)d->kh * d->kw * plan->k_pad * plan->n_pad * sizeof(_Float16));
+        // one fp16 plane, plus the residual plane in float32-equivalent mode
+        plan->wprep_bytes = round256((size_t)(plan->passes == 3 ? 2 : 1) * d->kh * d->kw * plan->k_pad * plan->n_pad * sizeof(_Float16));
     } else {
         plan->family = kDirect;
         plan->wprep_bytes = round256((size_t)d->kh * d->kw * cg * d->c_out * sizeof(float));
@@ -184,7 +185,10 @@ __global__ __launch_bounds__(256) void k_prepare(const float* __restrict__ w, vo
         const int kq = (kk & 15) >> 2, j = (kk >> 4) * 4 + (kk & 3);
         const size_t ntiles = (size_t)(plane / ((int64_t)KS * 32 * 16));
         const size_t at = ((((size_t)(kh * KW + kw) * ntiles + nt) * KS + ks) * 64 + (size_t)(kq * 16 + row)) * 8 + j;
-        reinterpret_cast<_Float16*>(prep)[at] = (_Float16)(16.0f * q);
+        const float v = 16.0f * q;
+        const _Float16 hi = (_Float16)v;
+        reinterpret_cast<_Float16*>(prep)[at] = hi;
+        if (ldo) reinterpret_cast<_Float16*>(prep)[(size_t)KH * KW * plane + at] = (_Float16)(v - (float)hi);  // ldo != 0: residual plane
     } else {
         // MFMA 16x16x32 A-fragment order: tile (o/16, k/32), lane = kq*16 + o%16 where lane-quarter kq
         // holds k%32 in {kq*4..kq*4+3} (elements 0-3) and {16+kq*4..16+kq*4+3} (elements 4-7): conv_pw.hip
@@ -210,12 +214,14 @@ int launch_prepare_weights(const slfp_conv2d_desc& d, const ConvPlan& p, const f
     const int KS = p.family == kStemMfma ? (int)p.k_pad : (int)(p.k_pad / 32);
     const unsigned grid = (unsigned)ceil_div(total, 256);
     const ScaleDiv sd = make_scale_div(d.kw_scale);
+    // depthwise: row pitch of the [9][C] table (padded channel count); dense MFMA: 1 = also write the residual plane
+    const int ldo = p.family == kDenseMfma ? (p.passes == 3 ? 1 : 0) : (int)p.cpo;
     if (p.fmt_w == kFmtW8)
         hipLaunchKernelGGL((k_prepare<kFmtW8>), dim3(grid), dim3(256), 0, stream, w_oihw, wprep, weight_q_oihw, total,
-                           (int)d.c_out, Cg, (int)d.kh, (int)d.kw, sd, (int)p.family, KS, plane, (int)p.cpo);
+                           (int)d.c_out, Cg, (int)d.kh, (int)d.kw, sd, (int)p.family, KS, plane, ldo);
     else
         hipLaunchKernelGGL((k_prepare<kFmtSfp7>), dim3(grid), dim3(256), 0, stream, w_oihw, wprep, weight_q_oihw, total,
-                           (int)d.c_out, Cg, (int)d.kh, (int)d.kw, sd, (int)p.family, KS, plane, (int)p.cpo);
+                           (int)d.c_out, Cg, (int)d.kh, (int)d.kw, sd, (int)p.family, KS, plane, ldo);
     return check_launch("slfp weight prepare kernel");
 }
 
@@ -228,7 +234,7 @@ static const char* family_name(const ConvPlan& p, const slfp_conv2d_desc& d) {
     switch (p.family) {
         case kDw3x3: return "dw3x3_nhwc";
         case kPointwise: return p.fmt_act == kFmtSfp7 ? "pw_mfma_f16_exact" : (p.passes == 3 ? "pw_mfma_f16x3" : "pw_mfma_f16x1");
-        case kDenseMfma: return p.fmt_act == kFmtSfp7 ? "dense_mfma_f16_exact" : "dense_mfma_f16x1";
+        case kDenseMfma: return p.fmt_act == kFmtSfp7 ? "dense_mfma_f16_exact" : (p.passes == 3 ? "dense_mfma_f16x3" : "dense_mfma_f16x1");
         case kStemMfma: return p.fmt_act == kFmtSfp7 ? "stem_mfma_f16_exact" : "stem_mfma_f16x1";
         case kStemSmall: return p.fmt_act == kFmtSfp7 ? "stem_small_mfma_f16_exact" : "stem_small_mfma_f16x1";
         default: return "direct_nhwc";
@@ -278,7 +284,7 @@ size_t slfp_conv2d_workspace_bytes(const slfp_conv2d_desc* d) {
     size_t b = 0;
     if (d->x_layout == SLFP_LAYOUT_NCHW) b += round256((size_t)d->n * d->c_in * d->h * d->w * sizeof(float));
     if (d->y_layout == SLFP_LAYOUT_NCHW) b += round256((size_t)d->n * d->c_out * p.h_out * p.w_out * sizeof(float));
-    if (p.family == kDenseMfma) b += dense_mfma_workspace_bytes(*d);  // the input encoded once to fp16
+    if (p.family == kDenseMfma) b += dense_mfma_workspace_bytes(*d, p.passes);  // the input encoded once to fp16
     if (p.family == kStemMfma) b += stem_mfma_workspace_bytes(*d, p.w_out);
     if (p.repad) {
         if (p.cpi != d->c_in) b += round256((size_t)d->n * d->h * d->w * p.cpi * sizeof(float));

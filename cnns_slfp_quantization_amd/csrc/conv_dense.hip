@@ -22,8 +22,9 @@
 //        the other's MFMA time); dense_choose() picks the tiling per layer;
 //      * fp16 operands (both pre-scaled by 2^4, see conv_pw.hip), float32 accumulation, the
 //        reference's (out*Ka)*Kw roundings and the optional fused BN/ReLU post-op in the epilogue.
-// Single-pass fp16 (SLFP<3,4>: ~2.5e-4 tensor-relative, the north-star 1e-3 bar) or exact
-// (SFP<3,3>).  The float32-equivalent mode of these layers stays on k_direct.
+// Single-pass fp16 (SLFP<3,4>: ~2.5e-4 tensor-relative, the north-star 1e-3 bar), exact (SFP<3,3>), or
+// float32-equivalent (SLFP_MFMA_F16X3: hi + lo fp16 planes of both operands, 3 MFMAs per tile; stride-2
+// layers, whose halo tiles do not fit twice in LDS, stay on k_direct in that mode).
 #include "slfp_device.hpp"
 #include "slfp_host.hpp"
 
@@ -38,6 +39,8 @@ constexpr int kDnTW = 16;  // output columns per tile = one MFMA pixel tile
 
 struct DenseParams {
     const _Float16* xe;  // pre-encoded input, NHWC with C padded to Cp (k_dense_encode)
+    const _Float16* xlo; // PASSES == 3: its fp16 residual plane
+    const _Float16* wlo; // PASSES == 3: the weights' residual plane (same fragment order as w)
     const unsigned char* zero_page;  // 256 zero bytes: DMA source for padding pixels / channels past Cp
     const _Float16* w;   // [tap][n_tile][k_step][64 lanes][8]
     const float* bias;
@@ -73,8 +76,10 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {  // 64 lanes x 
 // Pre-pass: x (float32 NHWC) -> xe = fp16(16 * QA(x / Ka)), NHWC with C padded to a multiple of 32
 // and, inside every 32-channel group, 16-byte chunk j = channels {4j..4j+3, 16+4j..16+4j+3}: exactly
 // the 8 k-values lane-quarter j of a 16x16x32 MFMA B fragment holds.  One thread per chunk.
+// lo != nullptr (float32-equivalent mode): also writes the fp16 residual v - fp32(fp16(v)) to a second plane.
 template <int FMT>
 __global__ __launch_bounds__(256) void k_dense_encode(const float* __restrict__ x, _Float16* __restrict__ xe,
+                                                      _Float16* __restrict__ lo,
                                                       unsigned char* __restrict__ zero_page, int64_t n_chunks16,
                                                       int C, int Cp, const ScaleDiv sd) {
     __shared__ uint32_t sT[16];
@@ -91,25 +96,33 @@ __global__ __launch_bounds__(256) void k_dense_encode(const float* __restrict__ 
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
     if (c0 < C) a = *reinterpret_cast<const float4*>(xp + c0);
     if (c0 + 16 < C) b = *reinterpret_cast<const float4*>(xp + c0 + 16);
-    half8 h;
-    h[0] = (_Float16)quantize_scaled<FMT, 4>(a.x, sd, sT); h[1] = (_Float16)quantize_scaled<FMT, 4>(a.y, sd, sT);
-    h[2] = (_Float16)quantize_scaled<FMT, 4>(a.z, sd, sT); h[3] = (_Float16)quantize_scaled<FMT, 4>(a.w, sd, sT);
-    h[4] = (_Float16)quantize_scaled<FMT, 4>(b.x, sd, sT); h[5] = (_Float16)quantize_scaled<FMT, 4>(b.y, sd, sT);
-    h[6] = (_Float16)quantize_scaled<FMT, 4>(b.z, sd, sT); h[7] = (_Float16)quantize_scaled<FMT, 4>(b.w, sd, sT);
-    if (c0 >= C) h = half8{0, 0, 0, 0, 0, 0, 0, 0};              // quantize(0) is +0 anyway; keep the pad exact
-    else if (c0 + 16 >= C) { h[4] = 0; h[5] = 0; h[6] = 0; h[7] = 0; }
+    float v[8] = {quantize_scaled<FMT, 4>(a.x, sd, sT), quantize_scaled<FMT, 4>(a.y, sd, sT),
+                  quantize_scaled<FMT, 4>(a.z, sd, sT), quantize_scaled<FMT, 4>(a.w, sd, sT),
+                  quantize_scaled<FMT, 4>(b.x, sd, sT), quantize_scaled<FMT, 4>(b.y, sd, sT),
+                  quantize_scaled<FMT, 4>(b.z, sd, sT), quantize_scaled<FMT, 4>(b.w, sd, sT)};
+    half8 h, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const bool pad = c0 + (j >> 2) * 16 >= C;   // quantize(0) is +0 anyway; keep the pad exact
+        h[j] = pad ? (_Float16)0.f : (_Float16)v[j];
+        l[j] = pad ? (_Float16)0.f : (_Float16)(v[j] - (float)h[j]);
+    }
+    if (lo) *reinterpret_cast<half8*>(lo + idx * 8) = l;
     *reinterpret_cast<half8*>(xe + idx * 8) = h;
 }
 
 // WM x WN = 8 waves; MT = output rows per wave.  Both operands arrive by LDS-DMA: no VALU work
 // in the main loop beyond addresses.
-template <int WM, int WN, int MT>
-__global__ __launch_bounds__(kDnThreads, (MT == 4 ? 2 : 4)) void k_dense_mfma(const DenseParams p) {
+// PASSES == 3 (float32-equivalent): both operands carry an fp16 residual plane (hi + lo), staged next to
+// the hi planes, and every tile takes 3 MFMAs (lo*hi + hi*lo + hi*hi), as the pointwise kernels do.
+template <int WM, int WN, int MT, int PASSES>
+__global__ __launch_bounds__(kDnThreads, (MT == 4 || PASSES == 3 ? 2 : 4)) void k_dense_mfma(const DenseParams p) {
     static_assert(WM * WN == 8, "8 waves");
-    constexpr int TH = WM * MT, BN = WN * 64, WT = BN * 128;  // WT: bytes of one tap's weight tile
+    constexpr int TH = WM * MT, BN = WN * 64, WT = BN * 128;  // WT: bytes of one tap's weight tile (one plane)
+    constexpr int PL = PASSES == 3 ? 2 : 1;                   // operand planes
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* wbuf = smem;            // [2][WT]
-    unsigned char* xsb = wbuf + 2 * WT;    // [2][x_pieces * 1 KiB]   (8 halo pixels x 128 B per piece)
+    unsigned char* wbuf = smem;                 // [2 buffers][PL planes][WT]
+    unsigned char* xsb = wbuf + 2 * PL * WT;    // [2 buffers][PL planes][x_pieces * 1 KiB]   (8 halo pixels x 128 B per piece)
     const uint32_t xbytes = (uint32_t)p.x_pieces * 1024u;
 
     uint32_t b = xcd_remap(blockIdx.x, p.nblocks);   // channel slice slowest: an XCD's L2 holds one W slice
@@ -125,6 +138,7 @@ __global__ __launch_bounds__(kDnThreads, (MT == 4 ? 2 : 4)) void k_dense_mfma(co
     // ---- halo tile: piece q of a chunk = 8 consecutive halo pixels x 64 channels (fp16), one DMA.
     // lane -> (pixel pc*8 + lane/8, LDS slot lane%8); the slot holds 16-byte chunk slot ^ swz(pixel).
     const unsigned char* xen = reinterpret_cast<const unsigned char*>(p.xe) + (size_t)n * p.H * p.W * p.Cp * 2;
+    const ptrdiff_t x_lo_off = PASSES == 3 ? reinterpret_cast<const unsigned char*>(p.xlo) - reinterpret_cast<const unsigned char*>(p.xe) : 0;
     auto stage_x = [&](int pc, int chunk, int buf) {
         const int pix = pc * 8 + (lane >> 3);
         const int ih = pix / p.IW, iw = pix - ih * p.IW;
@@ -133,7 +147,9 @@ __global__ __launch_bounds__(kDnThreads, (MT == 4 ? 2 : 4)) void k_dense_mfma(co
         const int kbyte = chunk * 128 + c16 * 16;
         const bool inb = pix < p.n_pix && (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W && kbyte < p.Cp * 2;
         const unsigned char* src = inb ? xen + ((size_t)(gh * p.W + gw) * p.Cp) * 2 + kbyte : p.zero_page + (lane & 7) * 16;
-        glds16(src, xsb + (size_t)buf * xbytes + (size_t)pc * 1024);
+        glds16(src, xsb + (size_t)buf * PL * xbytes + (size_t)pc * 1024);
+        if constexpr (PASSES == 3)
+            glds16(inb ? src + x_lo_off : src, xsb + ((size_t)buf * PL + 1) * xbytes + (size_t)pc * 1024);
     };
 
     // ---- weight tap tile: BN/8 pieces of 1 KiB (channel tile, k-step), WN per wave
@@ -145,7 +161,9 @@ __global__ __launch_bounds__(kDnThreads, (MT == 4 ? 2 : 4)) void k_dense_mfma(co
             int nt = nt0 + (pc >> 1);
             nt = nt < p.n_tiles ? nt : p.n_tiles - 1;         // tiles past C_out: clamp (results never stored)
             const size_t o = (((size_t)tap * p.n_tiles + nt) * p.KS + (size_t)chunk * 2 + (pc & 1)) * 1024 + (size_t)lane * 16;
-            glds16(reinterpret_cast<const unsigned char*>(p.w) + o, wbuf + (size_t)buf * WT + (size_t)pc * 1024);
+            glds16(reinterpret_cast<const unsigned char*>(p.w) + o, wbuf + (size_t)buf * PL * WT + (size_t)pc * 1024);
+            if constexpr (PASSES == 3)
+                glds16(reinterpret_cast<const unsigned char*>(p.wlo) + o, wbuf + ((size_t)buf * PL + 1) * WT + (size_t)pc * 1024);
         }
     };
 
@@ -171,19 +189,24 @@ __global__ __launch_bounds__(kDnThreads, (MT == 4 ? 2 : 4)) void k_dense_mfma(co
     int wb = 0, xb = 0;
     for (int chunk = 0; chunk < n_chunks; ++chunk) {
         const bool more_chunks = chunk + 1 < n_chunks;
-        const unsigned char* xs = xsb + (size_t)xb * xbytes;
+        const unsigned char* xs = xsb + (size_t)xb * PL * xbytes;
         for (int tap = 0; tap < n_taps; ++tap) {
             const int kh = tap / p.KW, kw = tap - kh * p.KW;
-            const unsigned char* wt = wbuf + (size_t)wb * WT + (size_t)(wn * 4) * 2048 + lane * 16;
-            half8 wf[2][4], xf[2][MT];
+            const unsigned char* wt = wbuf + (size_t)wb * PL * WT + (size_t)(wn * 4) * 2048 + lane * 16;
+            half8 wf[2][4], xf[2][MT], wl[PASSES == 3 ? 2 : 1][4], xl[PASSES == 3 ? 2 : 1][MT];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) wf[ks][j] = *reinterpret_cast<const half8*>(wt + j * 2048 + ks * 1024);
+                for (int j = 0; j < 4; ++j) {
+                    wf[ks][j] = *reinterpret_cast<const half8*>(wt + j * 2048 + ks * 1024);
+                    if constexpr (PASSES == 3) wl[ks][j] = *reinterpret_cast<const half8*>(wt + WT + j * 2048 + ks * 1024);
+                }
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
                     const int row = ((wm * MT + i) * p.S + kh) * p.IW + col * p.S + kw;
-                    xf[ks][i] = *reinterpret_cast<const half8*>(xs + dn_x_off(row, ks * 4 + kq));
+                    const uint32_t off = dn_x_off(row, ks * 4 + kq);
+                    xf[ks][i] = *reinterpret_cast<const half8*>(xs + off);
+                    if constexpr (PASSES == 3) xl[ks][i] = *reinterpret_cast<const half8*>(xs + xbytes + off);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -212,8 +235,13 @@ __global__ __launch_bounds__(kDnThreads, (MT == 4 ? 2 : 4)) void k_dense_mfma(co
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < 4; ++j) {
+                        if constexpr (PASSES == 3) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[ks][j], xf[ks][i], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][j], xl[ks][i], acc[i][j], 0, 0, 0);
+                        }
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][j], xf[ks][i], acc[i][j], 0, 0, 0);
+                    }
             wb ^= 1;
         }
         xb ^= 1;
@@ -253,16 +281,16 @@ static const DenseCfg kDenseCfgs[] = {{2, 4, 4}, {4, 2, 4}, {4, 2, 2}, {4, 2, 1}
 
 struct DenseGeom { DenseCfg cfg; int ih, iw, pieces, per_tap; size_t lds; int occ; };
 
-static bool dense_cfg_geometry(const slfp_conv2d_desc& d, const DenseCfg& c, DenseGeom* g) {
+static bool dense_cfg_geometry(const slfp_conv2d_desc& d, const DenseCfg& c, int planes, DenseGeom* g) {
     const int S = d.stride_h, th = c.wm * c.mt, taps = (int)(d.kh * d.kw);
     g->cfg = c;
     g->ih = (th - 1) * S + (int)d.kh;
     g->iw = (kDnTW - 1) * S + (int)d.kw;
     g->pieces = (g->ih * g->iw + 7) / 8;
     g->per_tap = (int)ceil_div(ceil_div(g->pieces, 8), taps - 1);  // all slices issued before the last tap
-    g->lds = 2 * (size_t)c.wn * 64 * 128 + 2 * (size_t)g->pieces * 1024;
+    g->lds = (size_t)planes * (2 * (size_t)c.wn * 64 * 128 + 2 * (size_t)g->pieces * 1024);
     // MT 4 tilings hold 64 accumulator VGPRs + fragments: compiled for one workgroup per CU; the others for two
-    g->occ = c.mt == 4 ? 1 : (g->lds <= 80 * 1024 ? 2 : 1);
+    g->occ = (c.mt == 4 || planes == 2) ? 1 : (g->lds <= 80 * 1024 ? 2 : 1);
     return g->lds <= 160 * 1024;
 }
 
@@ -270,12 +298,12 @@ static bool dense_cfg_geometry(const slfp_conv2d_desc& d, const DenseCfg& c, Den
 // factor fitted to measured layer times (VGG-16 / ResNet-50 shapes, profiles/dense_cfg_sweep.sh):
 // small wave tiles re-read fragments and hit the barrier more often per MFMA, one-workgroup-per-CU
 // tilings have nobody to overlap their DMA waits with.
-static bool dense_choose(const slfp_conv2d_desc& d, int64_t h_out, int64_t w_out, DenseGeom* best) {
+static bool dense_choose(const slfp_conv2d_desc& d, int planes, int64_t h_out, int64_t w_out, DenseGeom* best) {
     double best_cost = 0;
     bool found = false;
     for (const DenseCfg& c : kDenseCfgs) {
         DenseGeom g;
-        if (!dense_cfg_geometry(d, c, &g)) continue;
+        if (!dense_cfg_geometry(d, c, planes, &g)) continue;
         const int th = c.wm * c.mt, bn = c.wn * 64;
         const int64_t blocks = d.n * ceil_div(h_out, th) * ceil_div(w_out, kDnTW) * ceil_div(d.c_out, bn);
         const int64_t per_cu = ceil_div(blocks, 256);
@@ -288,28 +316,32 @@ static bool dense_choose(const slfp_conv2d_desc& d, int64_t h_out, int64_t w_out
     return found;
 }
 
+static int dense_planes(const slfp_conv2d_desc& d, int passes) { return (d.qbits == 8 && passes == 3) ? 2 : 1; }
+
 bool dense_mfma_applicable(const slfp_conv2d_desc& d, int passes) {
     if (d.groups != 1 || d.kh * d.kw <= 1 || d.dil_h != 1 || d.dil_w != 1) return false;
     if (d.stride_h != d.stride_w || d.stride_h > 2) return false;
     if (d.c_in % 4 || d.c_in < 16 || d.c_out % 4) return false;
-    if (d.qbits == 8 && passes == 3) return false;  // the float32-equivalent mode stays on k_direct
     if ((int64_t)d.h * d.w * (d.c_in + 31) >= (1ll << 30)) return false;
     DenseGeom g;
     for (const DenseCfg& c : kDenseCfgs)
-        if (dense_cfg_geometry(d, c, &g)) return true;
-    return false;
+        if (dense_cfg_geometry(d, c, dense_planes(d, passes), &g)) return true;
+    return false;  // (float32-equivalent mode: stride-2 halo tiles do not fit twice -> k_direct)
 }
 
 static int64_t dense_cp(const slfp_conv2d_desc& d) { return ceil_div(d.c_in, 32) * 32; }
 
-// workspace = [256 B zero page][pre-encoded input: N*H*W*Cp fp16]
-size_t dense_mfma_workspace_bytes(const slfp_conv2d_desc& d) {
-    return 256 + (((size_t)d.n * d.h * d.w * dense_cp(d) * sizeof(_Float16)) + 255 & ~(size_t)255);
+// workspace = [256 B zero page][pre-encoded input: N*H*W*Cp fp16][its residual plane in float32-equivalent mode]
+static size_t dense_plane_bytes(const slfp_conv2d_desc& d) {
+    return (((size_t)d.n * d.h * d.w * dense_cp(d) * sizeof(_Float16)) + 255) & ~(size_t)255;
+}
+size_t dense_mfma_workspace_bytes(const slfp_conv2d_desc& d, int passes) {
+    return 256 + (size_t)dense_planes(d, passes) * dense_plane_bytes(d);
 }
 
-template <int WM, int WN, int MT>
-static int launch_dense_t(DenseParams& p, size_t lds, hipStream_t stream) {
-    auto fn = k_dense_mfma<WM, WN, MT>;
+template <int WM, int WN, int MT, int PASSES>
+static int launch_dense_tp(DenseParams& p, size_t lds, hipStream_t stream) {
+    auto fn = k_dense_mfma<WM, WN, MT, PASSES>;
     static bool lds_raised = false;  // > 64 KiB of dynamic LDS needs the opt-in once per kernel
     if (!lds_raised) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -320,28 +352,36 @@ static int launch_dense_t(DenseParams& p, size_t lds, hipStream_t stream) {
     return check_launch("slfp dense MFMA conv kernel");
 }
 
+template <int WM, int WN, int MT>
+static int launch_dense_t(DenseParams& p, size_t lds, int planes, hipStream_t stream) {
+    return planes == 2 ? launch_dense_tp<WM, WN, MT, 3>(p, lds, stream) : launch_dense_tp<WM, WN, MT, 1>(p, lds, stream);
+}
+
 int launch_dense_mfma(const slfp_conv2d_desc& d, const ConvPlan& plan, const float* x, const void* wblob,
                       const float* bias, const PostOp& post, float* y, void* workspace, hipStream_t stream) {
     DenseGeom g;
-    if (!dense_choose(d, plan.h_out, plan.w_out, &g)) return fail(SLFP_ERR_UNSUPPORTED, "dense MFMA conv: no tiling fits");
+    const int planes = dense_planes(d, plan.passes);
+    if (!dense_choose(d, planes, plan.h_out, plan.w_out, &g)) return fail(SLFP_ERR_UNSUPPORTED, "dense MFMA conv: no tiling fits");
     if (!workspace) return fail(SLFP_ERR_BAD_ARG, "dense MFMA conv: workspace required (slfp_conv2d_workspace_bytes)");
     // ---- pass 1: encode the input once (every element is reused KH*KW * C_out times by pass 2)
     unsigned char* zero_page = reinterpret_cast<unsigned char*>(workspace);
     _Float16* xe = reinterpret_cast<_Float16*>(zero_page + 256);
+    _Float16* xlo = planes == 2 ? reinterpret_cast<_Float16*>(zero_page + 256 + dense_plane_bytes(d)) : nullptr;
     const int cp = (int)dense_cp(d);
     const int64_t n_chunks16 = d.n * d.h * d.w * (cp / 8);
     const ScaleDiv sd = make_scale_div(d.ka, 4);
     const unsigned egrid = (unsigned)ceil_div(n_chunks16, 256);
     if (plan.fmt_act == kFmtAct8)
-        hipLaunchKernelGGL((k_dense_encode<kFmtAct8>), dim3(egrid), dim3(256), 0, stream, x, xe, zero_page, n_chunks16, (int)d.c_in, cp, sd);
+        hipLaunchKernelGGL((k_dense_encode<kFmtAct8>), dim3(egrid), dim3(256), 0, stream, x, xe, xlo, zero_page, n_chunks16, (int)d.c_in, cp, sd);
     else
-        hipLaunchKernelGGL((k_dense_encode<kFmtSfp7>), dim3(egrid), dim3(256), 0, stream, x, xe, zero_page, n_chunks16, (int)d.c_in, cp, sd);
+        hipLaunchKernelGGL((k_dense_encode<kFmtSfp7>), dim3(egrid), dim3(256), 0, stream, x, xe, xlo, zero_page, n_chunks16, (int)d.c_in, cp, sd);
     int rc = check_launch("slfp dense encode kernel");
     if (rc != SLFP_OK) return rc;
     // ---- pass 2: implicit GEMM
     DenseParams p;
-    p.xe = xe; p.zero_page = zero_page;
+    p.xe = xe; p.xlo = xlo; p.zero_page = zero_page;
     p.w = reinterpret_cast<const _Float16*>(wblob); p.bias = bias; p.y = y; p.post = post;
+    p.wlo = p.w + (size_t)d.kh * d.kw * plan.k_pad * plan.n_pad;   // second plane of the blob (float32-equivalent mode)
     p.N = (int)d.n; p.H = (int)d.h; p.W = (int)d.w; p.Cp = cp; p.O = (int)d.c_out;
     p.KH = (int)d.kh; p.KW = (int)d.kw; p.S = d.stride_h; p.ph = d.pad_h; p.pw = d.pad_w;
     p.Ho = (int)plan.h_out; p.Wo = (int)plan.w_out;
@@ -354,12 +394,12 @@ int launch_dense_mfma(const slfp_conv2d_desc& d, const ConvPlan& plan, const flo
     if (nblocks > 0x7FFFFFFF) return fail(SLFP_ERR_UNSUPPORTED, "dense MFMA conv: grid too large");
     p.nblocks = (uint32_t)nblocks;
     switch (g.cfg.wm * 100 + g.cfg.wn * 10 + g.cfg.mt) {
-        case 244: return launch_dense_t<2, 4, 4>(p, g.lds, stream);
-        case 424: return launch_dense_t<4, 2, 4>(p, g.lds, stream);
-        case 422: return launch_dense_t<4, 2, 2>(p, g.lds, stream);
-        case 421: return launch_dense_t<4, 2, 1>(p, g.lds, stream);
-        case 812: return launch_dense_t<8, 1, 2>(p, g.lds, stream);
-        default: return launch_dense_t<8, 1, 1>(p, g.lds, stream);
+        case 244: return launch_dense_t<2, 4, 4>(p, g.lds, planes, stream);
+        case 424: return launch_dense_t<4, 2, 4>(p, g.lds, planes, stream);
+        case 422: return launch_dense_t<4, 2, 2>(p, g.lds, planes, stream);
+        case 421: return launch_dense_t<4, 2, 1>(p, g.lds, planes, stream);
+        case 812: return launch_dense_t<8, 1, 2>(p, g.lds, planes, stream);
+        default: return launch_dense_t<8, 1, 1>(p, g.lds, planes, stream);
     }
 }
 

@@ -72,7 +72,7 @@ bool pointwise_stream_fits(int64_t k_pad, int64_t n_pad, int passes);
 // dense k x k implicit GEMM on MFMA (conv_dense.hip); wblob = [tap][n_tile][k_step][64][8] fp16;
 // `workspace` (dense_mfma_workspace_bytes) receives the input encoded once to fp16
 bool dense_mfma_applicable(const slfp_conv2d_desc& d, int passes);
-size_t dense_mfma_workspace_bytes(const slfp_conv2d_desc& d);
+size_t dense_mfma_workspace_bytes(const slfp_conv2d_desc& d, int passes);
 int launch_dense_mfma(const slfp_conv2d_desc& d, const ConvPlan& p, const float* x, const void* wblob,
                       const float* bias, const PostOp& post, float* y, void* workspace, hipStream_t stream);
 int launch_prepare_weights(const slfp_conv2d_desc& d, const ConvPlan& p, const float* w_oihw, void* wprep,

@@ -63,7 +63,11 @@ def test_kernel_selection_and_sizes():
     assert name(dense) == "dense_mfma_f16x1"                                     # dense k x k: implicit GEMM on MFMA
     assert L.slfp_conv2d_wprep_bytes(ctypes.byref(dense)) == 9 * 64 * 32 * 2     # [tap][C_in pad 64][C_out pad 16] fp16
     dense.mfma_passes = _lib.MFMA_F16X3
-    assert name(dense) == "direct_nhwc"                                          # float32-equivalent mode: fp32 kernel
+    assert name(dense) == "dense_mfma_f16x3"                                     # float32-equivalent mode: hi + lo planes
+    assert L.slfp_conv2d_wprep_bytes(ctypes.byref(dense)) == 2 * 9 * 64 * 32 * 2
+    assert L.slfp_conv2d_workspace_bytes(ctypes.byref(dense)) == 256 + 2 * (2 * 16 * 16 * 32 * 2)   # zero page + 2 fp16 planes, C padded to 32
+    dense.stride_h = dense.stride_w = 2
+    assert name(dense) == "direct_nhwc"                                          # stride-2 halo tiles do not fit twice
     dense.qbits = 7
     assert name(dense) == "dense_mfma_f16_exact"
     assert name(_desc(c_in=8, c_out=32, groups=1)) == "direct_nhwc"               # too few channels for a k-step

@@ -191,7 +191,7 @@ def test_conv_golden_cases(lib, dev, conv_golden, layout, passes):
         assert {"dw3x3_nhwc", "direct_nhwc", "pw_mfma_f16_exact", "passthrough"} <= seen, seen
         assert "stem_nhwc" in seen, seen
         assert ("pw_mfma_f16x3" if passes == 3 else "pw_mfma_f16x1") in seen, seen
-        assert "dense_mfma_f16_exact" in seen and (passes == 3 or "dense_mfma_f16x1" in seen), seen
+        assert "dense_mfma_f16_exact" in seen and ("dense_mfma_f16x3" if passes == 3 else "dense_mfma_f16x1") in seen, seen
         assert "stem_mfma_f16_exact" in seen and (passes == 3 or "stem_mfma_f16x1" in seen), seen
     finally:
         cf.options.mfma_passes = 0
@@ -357,9 +357,9 @@ def test_dense_kxk_mfma_vs_oracle(lib, dev):
         for qbits in (8, 7):
             kern, emax, el2 = _check_against_oracle(lib, dev, 3, C, H, O, k, s, p, 1, qbits, 0, seed=500 + i, bias=bias)
             assert kern == ("dense_mfma_f16x1" if qbits == 8 else "dense_mfma_f16_exact"), kern
-        # the float32-equivalent mode of these layers stays on the fp32 kernel
-        kern, _, _ = _check_against_oracle(lib, dev, 1, C, H, O, k, s, p, 1, 8, 3, seed=500 + i, bias=bias)
-        assert kern == "direct_nhwc"
+        # float32-equivalent mode: hi + lo fp16 planes, 3 MFMAs per tile (stride-2 halo tiles do not fit twice in LDS)
+        kern, _, _ = _check_against_oracle(lib, dev, 2, C, H, O, k, s, p, 1, 8, 3, seed=500 + i, bias=bias)
+        assert kern == ("dense_mfma_f16x3" if s == 1 else "direct_nhwc"), kern
 
 
 def test_channel_counts_not_multiple_of_4_vs_oracle(lib, dev):
@@ -440,6 +440,9 @@ def test_full_size_layers_of_the_other_configs_sampled_images(lib, dev, case):
     C, H, O, k, s, p, N, qbits = case
     g = C if (k == 3 and C == O == 58) else 1
     _check_against_oracle(lib, dev, N, C, H, O, k, s, p, g, qbits, 0, seed=900 + C + k, images=[0, N - 1], bias=(C == 64))
+    if C == 256:  # the float32-equivalent mode of a big dense layer (hi + lo planes)
+        kern, _, _ = _check_against_oracle(lib, dev, N, C, H, O, k, s, p, g, 8, 3, seed=950, images=[N - 1])
+        assert kern == "dense_mfma_f16x3"
 
 
 def test_run_to_run_determinism_at_full_size(lib, dev):
