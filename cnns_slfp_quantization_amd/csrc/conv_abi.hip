@@ -46,7 +46,7 @@ static int make_plan_core(const slfp_conv2d_desc* d, ConvPlan* plan) {
     const bool sq_stride = d->stride_h == d->stride_w;
     if (d->groups == d->c_in && d->c_out == d->c_in && d->kh == 3 && d->kw == 3 && d->dil_h == 1 && d->dil_w == 1 &&
         sq_stride && (d->stride_h == 1 || d->stride_h == 2) && d->pad_h == d->pad_w && d->pad_h <= 2 &&
-        (d->c_in % 4) == 0) {
+        (d->c_in % 2) == 0) {   // multiples of 4: 16-byte lanes; other even counts (58): 8-byte lanes
         plan->family = kDw3x3;
         plan->wprep_bytes = round256((size_t)9 * d->c_in * sizeof(float));
     } else if (d->kh == 1 && d->kw == 1 && d->groups == 1 && d->pad_h == 0 && d->pad_w == 0 && sq_stride &&

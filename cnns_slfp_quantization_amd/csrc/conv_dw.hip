@@ -36,12 +36,21 @@ struct DwParams {
     uint32_t nblocks;
 };
 
+// V floats per lane: 4 (16-byte accesses) or 2 (channel counts that are even but not a multiple of 4,
+// ShuffleNetV2's 58: pixel rows are only 8-byte aligned).
+template <int V>
+struct alignas(V * 4) DwVec {
+    float v[V];
+};
+
 // CBT / IWT > 0: channel-group width and input-tile width known at compile time (the MobileNetV1
 // tiles): every LDS offset becomes an immediate and the row-wrap arithmetic folds away.
-template <int FMT, int S, int CBT, int IWT>
+template <int FMT, int S, int CBT, int IWT, int V = 4>
 __global__ __launch_bounds__(kDwThreads) void k_dw3x3(const float* __restrict__ x, const float* __restrict__ wq,
                                                       const float* __restrict__ bias, float* __restrict__ y,
                                                       const DwParams p) {
+    using Vec = DwVec<V>;
+    constexpr int VSH = V == 4 ? 0 : 1;   // log2(4 / V): lanes per pixel double with 2-float lanes
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* sT = reinterpret_cast<uint32_t*>(smem);      // 16 dwords
     float* tile = reinterpret_cast<float*>(smem + 64);     // [IH][IW][CB]
@@ -49,7 +58,7 @@ __global__ __launch_bounds__(kDwThreads) void k_dw3x3(const float* __restrict__ 
     const int CB = CBT > 0 ? CBT : p.CB;
     const int IW = IWT > 0 ? IWT : p.IW;
     const int IWh = (IW + 1) / 2;
-    const int cb4_shift = CBT == 32 ? 3 : (CBT == 64 ? 4 : p.cb4_shift);
+    const int cb4_shift = (CBT == 32 ? 3 : (CBT == 64 ? 4 : p.cb4_shift)) + VSH;  // log2(lanes per pixel)
     const int dp = kDwThreads >> cb4_shift;  // pixels between two items of a thread
     const int in_step_h = dp / IW, in_step_w = dp - in_step_h * IW;
 
@@ -63,28 +72,37 @@ __global__ __launch_bounds__(kDwThreads) void k_dw3x3(const float* __restrict__ 
 
     const int cb4 = 1 << cb4_shift;
     const int my_c4 = threadIdx.x & (cb4 - 1);  // constant per thread: cb4 divides the block size
-    const int my_c = cg * CB + my_c4 * 4;
+    const int my_c = cg * CB + my_c4 * V;
     const bool c_live = my_c < p.C;
     const int pix0 = threadIdx.x >> cb4_shift;
     const int h_in0 = th * p.TH * S - p.pad, w_in0 = tw * p.TW * S - p.pad;
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    Vec zero;
+#pragma unroll
+    for (int e = 0; e < V; ++e) zero.v[e] = 0.f;
 
-    // this thread's 4 channels x 9 taps: issued first so that their (L2) latency hides under the tile loads
-    float4 wt[9];
-    float4 bq = zero4;
+    // this thread's V channels x 9 taps: issued first so that their (L2) latency hides under the tile loads
+    Vec wt[9];
+    Vec bq = zero;
+    // fused BN/ReLU vectors of this thread's channels: loaded once, not per output
+    Vec psc, psh;
+#pragma unroll
+    for (int e = 0; e < V; ++e) { psc.v[e] = 1.f; psh.v[e] = 0.f; }
     if (c_live) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const float4*>(wq + (size_t)t * p.C + my_c);
+        for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const Vec*>(wq + (size_t)t * p.C + my_c);
         if (bias) {  // bias_q = bias / Ka / Kw (utils/conv2d_func.py:44)
-            const float4 bb = *reinterpret_cast<const float4*>(bias + my_c);
-            bq = make_float4((bb.x / p.ka) / p.kw, (bb.y / p.ka) / p.kw, (bb.z / p.ka) / p.kw, (bb.w / p.ka) / p.kw);
+            const Vec bb = *reinterpret_cast<const Vec*>(bias + my_c);
+#pragma unroll
+            for (int e = 0; e < V; ++e) bq.v[e] = (bb.v[e] / p.ka) / p.kw;
+        }
+        if (p.post.scale) {
+            psc = *reinterpret_cast<const Vec*>(p.post.scale + my_c);
+            psh = *reinterpret_cast<const Vec*>(p.post.shift + my_c);
         }
     } else {
 #pragma unroll
-        for (int t = 0; t < 9; ++t) wt[t] = zero4;
+        for (int t = 0; t < 9; ++t) wt[t] = zero;
     }
-    // fused BN/ReLU vectors of this thread's 4 channels: loaded once, not per output
-    const PostVec pv = c_live ? post_load(p.post, my_c) : PostVec{zero4, zero4};
     __syncthreads();
 
     // ---------------- LOAD + ENCODE phase ----------------
@@ -97,12 +115,12 @@ __global__ __launch_bounds__(kDwThreads) void k_dw3x3(const float* __restrict__ 
         int gh = h_in0 + ih, gw = w_in0 + iw;
         const float* xn = x + (size_t)n * p.H * p.W * p.C + my_c;
         int goff = (gh * p.W + gw) * p.C;                               // may be negative outside the image
-        int lrow = ih * IW * CB + my_c4 * 4;                         // LDS offset of the tile row
+        int lrow = ih * IW * CB + my_c4 * V;                         // LDS offset of the tile row
         const int g_step = (in_step_h * p.W + in_step_w) * p.C, g_wrap = (p.W - IW) * p.C;
         const int l_step = in_step_h * IW * CB, l_wrap = IW * CB;
         constexpr int U = 8;  // loads kept in flight per thread (a 16x16x32 halo tile = 8 per thread: one batch)
         while (pix < n_pix) {
-            float4 v[U];
+            Vec v[U];
             int dst[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -110,8 +128,8 @@ __global__ __launch_bounds__(kDwThreads) void k_dw3x3(const float* __restrict__ 
                 const bool inb = live && c_live && (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W;
                 const int slot = (S == 2) ? ((iw & 1) * IWh + (iw >> 1)) : iw;
                 dst[u] = live ? lrow + slot * CB : -1;
-                v[u] = zero4;
-                if (inb) v[u] = *reinterpret_cast<const float4*>(xn + (uint32_t)goff);
+                v[u] = zero;
+                if (inb) v[u] = *reinterpret_cast<const Vec*>(xn + (uint32_t)goff);
                 pix += dp;
                 gh += in_step_h; gw += in_step_w; iw += in_step_w;
                 goff += g_step; lrow += l_step;
@@ -120,13 +138,11 @@ __global__ __launch_bounds__(kDwThreads) void k_dw3x3(const float* __restrict__ 
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (dst[u] < 0) continue;
-                float4 q;
+                Vec q;
                 // Q(0/Ka) == 0, so padded / out-of-range zeros go through the same path.
-                q.x = quantize_scaled<FMT>(v[u].x, p.sd, sT);
-                q.y = quantize_scaled<FMT>(v[u].y, p.sd, sT);
-                q.z = quantize_scaled<FMT>(v[u].z, p.sd, sT);
-                q.w = quantize_scaled<FMT>(v[u].w, p.sd, sT);
-                *reinterpret_cast<float4*>(tile + dst[u]) = q;
+#pragma unroll
+                for (int e = 0; e < V; ++e) q.v[e] = quantize_scaled<FMT>(v[u].v[e], p.sd, sT);
+                *reinterpret_cast<Vec*>(tile + dst[u]) = q;
             }
         }
     }
@@ -141,14 +157,14 @@ __global__ __launch_bounds__(kDwThreads) void k_dw3x3(const float* __restrict__ 
         int goh = th * p.TH + oh, gow = tw * p.TW + ow;
         float* yn = y + (size_t)n * p.Ho * p.Wo * p.C + my_c;
         int yoff = (goh * p.Wo + gow) * p.C;
-        int lbase = ((oh * S) * IW + (S == 1 ? ow : 0)) * CB + my_c4 * 4;  // tile offset of the window's first tap
+        int lbase = ((oh * S) * IW + (S == 1 ? ow : 0)) * CB + my_c4 * V;  // tile offset of the window's first tap
         const int y_step = (p.out_step_h * p.Wo + p.out_step_w) * p.C, y_wrap = (p.Wo - p.TW) * p.C;
         const int l_step = (p.out_step_h * S * IW + (S == 1 ? p.out_step_w : 0)) * CB;
         const int l_wrap = (S * IW - (S == 1 ? p.TW : 0)) * CB;
         const int row_pitch = IW * CB;
         for (; pix < n_pix; pix += dp) {
             if (goh < p.Ho && gow < p.Wo && c_live) {
-                float4 acc = bq;
+                Vec acc = bq;
 #pragma unroll
                 for (int kh = 0; kh < 3; ++kh) {
                     const float* row = tile + lbase + kh * row_pitch;
@@ -161,20 +177,21 @@ __global__ __launch_bounds__(kDwThreads) void k_dw3x3(const float* __restrict__ 
                             const int iw = ow * 2 + kw;
                             o = ((iw & 1) * IWh + (iw >> 1)) * CB;
                         }
-                        const float4 a = *reinterpret_cast<const float4*>(row + o);
-                        const float4 w = wt[kh * 3 + kw];
-                        acc.x = fmaf(a.x, w.x, acc.x);
-                        acc.y = fmaf(a.y, w.y, acc.y);
-                        acc.z = fmaf(a.z, w.z, acc.z);
-                        acc.w = fmaf(a.w, w.w, acc.w);
+                        const Vec a = *reinterpret_cast<const Vec*>(row + o);
+                        const Vec w = wt[kh * 3 + kw];
+#pragma unroll
+                        for (int e = 0; e < V; ++e) acc.v[e] = fmaf(a.v[e], w.v[e], acc.v[e]);
                     }
                 }
-                float4 r;  // (out * Ka) * Kw: two float32 roundings, as utils/conv2d_func.py:24
-                r.x = (acc.x * p.ka) * p.kw;
-                r.y = (acc.y * p.ka) * p.kw;
-                r.z = (acc.z * p.ka) * p.kw;
-                r.w = (acc.w * p.ka) * p.kw;
-                *reinterpret_cast<float4*>(yn + (uint32_t)yoff) = post_apply_v(r, p.post, pv);
+                Vec r;  // (out * Ka) * Kw: two float32 roundings, as utils/conv2d_func.py:24; then the fused BN / ReLU
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    float t = (acc.v[e] * p.ka) * p.kw;
+                    if (p.post.scale) t = __builtin_fmaf(t, psc.v[e], psh.v[e]);
+                    if (p.post.relu) t = fmaxf(t, 0.f);
+                    r.v[e] = t;
+                }
+                *reinterpret_cast<Vec*>(yn + (uint32_t)yoff) = r;
             }
             oh += p.out_step_h; goh += p.out_step_h;
             ow += p.out_step_w; gow += p.out_step_w;
@@ -210,12 +227,13 @@ int launch_dw3x3(const slfp_conv2d_desc& d, const ConvPlan& plan, const float* x
     // keep the halo tile within 40 KiB of LDS (>= 3 workgroups per CU)
     while (CB > 4 && (size_t)p.IH * p.IW * CB * sizeof(float) > 40 * 1024) CB /= 2;
     p.CB = CB;
-    p.cb4_shift = 0;
+    p.cb4_shift = 0;   // log2(CB / 4); the 2-float kernels add 1
     while ((4 << p.cb4_shift) < CB) ++p.cb4_shift;
     p.cgroups = (int)ceil_div(p.C, CB);
     p.pad = d.pad_h;
     p.IWh = (p.IW + 1) / 2;
-    const int dp = kDwThreads >> p.cb4_shift;
+    const bool v2 = (p.C % 4) != 0;   // even channel count (58): 8-byte lanes, twice as many lanes per pixel
+    const int dp = kDwThreads >> (p.cb4_shift + (v2 ? 1 : 0));
     p.out_step_h = dp / p.TW; p.out_step_w = dp % p.TW;
     p.sd = make_scale_div(d.ka);
     p.ka = d.ka; p.kw = d.kw_scale;
@@ -227,15 +245,20 @@ int launch_dw3x3(const slfp_conv2d_desc& d, const ConvPlan& plan, const float* x
     const size_t lds = 64 + (size_t)p.IH * p.IW * p.CB * sizeof(float);
     if (lds > 64 * 1024) return fail(SLFP_ERR_UNSUPPORTED, "dw3x3: tile needs %zu B of LDS", lds);
     const bool a8 = plan.fmt_act == kFmtAct8;
-#define SLFP_DW_LAUNCH(FMT, SS, CBT, IWT) \
-    hipLaunchKernelGGL((k_dw3x3<FMT, SS, CBT, IWT>), dim3(p.nblocks), dim3(kDwThreads), lds, stream, x, wq9c, bias, y, p)
-#define SLFP_DW_BY_FMT(SS, CBT, IWT) \
-    do { if (a8) SLFP_DW_LAUNCH(kFmtAct8, SS, CBT, IWT); else SLFP_DW_LAUNCH(kFmtSfp7, SS, CBT, IWT); } while (0)
-    if (S == 1 && p.CB == 32 && p.IW == 16) SLFP_DW_BY_FMT(1, 32, 16);      // 14x14 tiles (112..14 px layers)
-    else if (S == 1 && p.CB == 64 && p.IW == 9) SLFP_DW_BY_FMT(1, 64, 9);  // 7x7 images, >= 64 channels
-    else if (S == 2 && p.CB == 32 && p.IW == 15) SLFP_DW_BY_FMT(2, 32, 15); // 7x7 output tiles of stride-2 layers
-    else if (S == 1) SLFP_DW_BY_FMT(1, 0, 0);
-    else SLFP_DW_BY_FMT(2, 0, 0);
+#define SLFP_DW_LAUNCH(FMT, SS, CBT, IWT, VV) \
+    hipLaunchKernelGGL((k_dw3x3<FMT, SS, CBT, IWT, VV>), dim3(p.nblocks), dim3(kDwThreads), lds, stream, x, wq9c, bias, y, p)
+#define SLFP_DW_BY_FMT(SS, CBT, IWT, VV) \
+    do { if (a8) SLFP_DW_LAUNCH(kFmtAct8, SS, CBT, IWT, VV); else SLFP_DW_LAUNCH(kFmtSfp7, SS, CBT, IWT, VV); } while (0)
+    if (v2) {
+        if (S == 1 && p.CB == 32 && p.IW == 16) SLFP_DW_BY_FMT(1, 32, 16, 2);
+        else if (S == 1) SLFP_DW_BY_FMT(1, 0, 0, 2);
+        else SLFP_DW_BY_FMT(2, 0, 0, 2);
+    }
+    else if (S == 1 && p.CB == 32 && p.IW == 16) SLFP_DW_BY_FMT(1, 32, 16, 4);      // 14x14 tiles (112..14 px layers)
+    else if (S == 1 && p.CB == 64 && p.IW == 9) SLFP_DW_BY_FMT(1, 64, 9, 4);  // 7x7 images, >= 64 channels
+    else if (S == 2 && p.CB == 32 && p.IW == 15) SLFP_DW_BY_FMT(2, 32, 15, 4); // 7x7 output tiles of stride-2 layers
+    else if (S == 1) SLFP_DW_BY_FMT(1, 0, 0, 4);
+    else SLFP_DW_BY_FMT(2, 0, 0, 4);
 #undef SLFP_DW_BY_FMT
 #undef SLFP_DW_LAUNCH
     return check_launch("slfp dw3x3 kernel");

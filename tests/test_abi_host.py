@@ -39,7 +39,8 @@ def test_kernel_selection_and_sizes():
     name = lambda d: L.slfp_conv2d_kernel_name(ctypes.byref(d)).decode()
     assert name(_desc()) == "dw3x3_nhwc"
     assert name(_desc(stride_h=2, stride_w=2)) == "dw3x3_nhwc"
-    odd = _desc(c_in=58, c_out=58, groups=58)                                    # ShuffleNetV2 odd width:
+    assert name(_desc(c_in=58, c_out=58, groups=58)) == "dw3x3_nhwc"           # ShuffleNetV2 width 58: 8-byte lanes
+    odd = _desc(c_in=57, c_out=57, groups=57)                                    # odd width:
     assert name(odd) == "repad+dw3x3_nhwc"                                       # same kernel on channel-padded copies
     assert L.slfp_conv2d_wprep_bytes(ctypes.byref(odd)) == 2304                  # 9*60*4 rounded up to 256
     assert L.slfp_conv2d_workspace_bytes(ctypes.byref(odd)) == 2 * (2 * 16 * 16 * 60 * 4) + 3 * 256

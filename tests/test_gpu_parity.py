@@ -364,13 +364,14 @@ def test_dense_kxk_mfma_vs_oracle(lib, dev):
 
 def test_channel_counts_not_multiple_of_4_vs_oracle(lib, dev):
     """ShuffleNetV2's 58-channel branches (nets_imgnet/shufflenetv2.py): depthwise and 1x1 layers whose channel
-    count is not a multiple of 4 run the fast kernels on channel-padded copies; 24/116/232-channel depthwise
-    layers use 32-wide channel groups with a ragged last group."""
+    count is even but not a multiple of 4 use 8-byte lanes / accesses, odd counts run the fast kernels on
+    channel-padded copies; 24/116/232-channel depthwise layers use 32-wide channel groups with a ragged last group."""
     cases = [(58, 28, 58, 3, 1, 1, 58, False), (58, 29, 58, 3, 2, 1, 58, True), (58, 28, 58, 1, 1, 0, 1, False),
              (24, 28, 58, 1, 1, 0, 1, True), (58, 14, 116, 1, 1, 0, 1, False), (30, 9, 30, 3, 1, 1, 30, True),
              (24, 30, 24, 3, 2, 1, 24, False), (116, 15, 116, 3, 1, 1, 116, False), (232, 14, 232, 3, 2, 1, 232, True),
              (58, 15, 30, 1, 2, 0, 1, True), (27, 10, 58, 1, 1, 0, 1, True), (58, 9, 514, 1, 1, 0, 1, False),
-             (58, 5, 1026, 1, 1, 0, 1, True)]
+             (58, 5, 1026, 1, 1, 0, 1, True), (29, 17, 29, 3, 1, 1, 29, True), (58, 112, 58, 3, 1, 1, 58, False),
+             (58, 31, 58, 3, 2, 1, 58, True)]
     for i, (C, H, O, k, s, p, g, bias) in enumerate(cases):
         for qbits, passes in ((8, 0), (8, 3), (7, 0)):
             kern, emax, el2 = _check_against_oracle(lib, dev, 3, C, H, O, k, s, p, g, qbits, passes, seed=700 + i, bias=bias)
@@ -378,7 +379,7 @@ def test_channel_counts_not_multiple_of_4_vs_oracle(lib, dev):
                 planes = 2 if (passes == 3 and qbits == 8) else 1   # W must fit the LDS-resident stream kernel
                 native = C % 2 == 0 and O % 2 == 0 and 64 * (-(-O // 64) * 64) * 2 * planes <= 128 * 1024
                 assert kern.startswith("pw_mfma") if native else kern.startswith("repad+pw_mfma"), kern
-            elif C % 4:
+            elif C % 2:
                 assert kern == "repad+dw3x3_nhwc", kern
             else:
                 assert kern == "dw3x3_nhwc", kern
