@@ -341,7 +341,21 @@ __global__ __launch_bounds__(256) void k_stem_fixed(const float* __restrict__ x,
     const int gow = tw * kStemTW + col;
     if (gow >= p.Wo) return;
     float* yb = y + (((size_t)n * p.Ho + th * kStemTH + row0) * p.Wo + gow) * O + c4 * 4;
-    const PostVec pv = post_load(p.post, c4 * 4);  // once per thread, not per stored row
+    if (p.post.scale) {   // fused BN: the vectors once per thread (its own path: see conv_pw.hip, k_pw_tiled)
+        const PostVec pv = post_load(p.post, c4 * 4);
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            if (th * kStemTH + row0 + q < p.Ho) {
+                float4 r;
+                r.x = ((acc[q].x + bq.x) * p.s1) * p.s2;
+                r.y = ((acc[q].y + bq.y) * p.s1) * p.s2;
+                r.z = ((acc[q].z + bq.z) * p.s1) * p.s2;
+                r.w = ((acc[q].w + bq.w) * p.s1) * p.s2;
+                *reinterpret_cast<float4*>(yb + (uint32_t)(q * p.Wo * O)) = post_apply_v(r, p.post, pv);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < P; ++q) {
         if (th * kStemTH + row0 + q < p.Ho) {
@@ -350,7 +364,7 @@ __global__ __launch_bounds__(256) void k_stem_fixed(const float* __restrict__ x,
             r.y = ((acc[q].y + bq.y) * p.s1) * p.s2;
             r.z = ((acc[q].z + bq.z) * p.s1) * p.s2;
             r.w = ((acc[q].w + bq.w) * p.s1) * p.s2;
-            *reinterpret_cast<float4*>(yb + (uint32_t)(q * p.Wo * O)) = post_apply_v(r, p.post, pv);
+            *reinterpret_cast<float4*>(yb + (uint32_t)(q * p.Wo * O)) = post_apply(r, p.post, c4 * 4);
         }
     }
 }

@@ -142,13 +142,16 @@ __global__ __launch_bounds__(kStreamThreads) void k_pw_stream(const PwParams p) 
     // divisions) sit on the critical path of every 16-byte store: +12-38 % on these layers (bench.py --post).
     float* ep = reinterpret_cast<float*>(smem + 64 + (size_t)(PASSES == 3 ? 2 : 1) * wfrags * 1024);
     const int n_pad = p.n_tiles * 16;
-    for (int i = threadIdx.x; i < n_pad; i += kStreamThreads) {
-        const bool in = i < p.N;
-        ep[i] = (p.bias && in) ? 256.f * ((p.bias[i] / p.s1) / p.s2) : 0.f;
-        ep[n_pad + i] = (p.post.scale && in) ? p.post.scale[i] : 1.f;
-        ep[2 * n_pad + i] = (p.post.scale && in) ? p.post.shift[i] : 0.f;
+    const bool has_vec = p.bias != nullptr || p.post.scale != nullptr;   // wave-uniform
+    if (has_vec) {
+        for (int i = threadIdx.x; i < n_pad; i += kStreamThreads) {
+            const bool in = i < p.N;
+            ep[i] = (p.bias && in) ? 256.f * ((p.bias[i] / p.s1) / p.s2) : 0.f;
+            ep[n_pad + i] = (p.post.scale && in) ? p.post.scale[i] : 1.f;
+            ep[2 * n_pad + i] = (p.post.scale && in) ? p.post.shift[i] : 0.f;
+        }
+        __syncthreads();
     }
-    __syncthreads();
 
     const int lane = threadIdx.x & 63;
     const int col = lane & 15, kq = lane >> 4;
@@ -218,13 +221,18 @@ __global__ __launch_bounds__(kStreamThreads) void k_pw_stream(const PwParams p) 
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[ks], acc, 0, 0, 0);
             }
             const int n = j * 16 + kq * 4;
-            const float4 bq = *reinterpret_cast<const float4*>(ep + n);
-            float4 r = epilogue(acc, bq, p.s1x, p.s2);
-            if (p.post.scale) {
+            float4 r;
+            if (has_vec) {   // bias and/or fused BN: all three vectors from LDS
+                const float4 bq = *reinterpret_cast<const float4*>(ep + n);
                 const float4 sc = *reinterpret_cast<const float4*>(ep + n_pad + n);
                 const float4 sh = *reinterpret_cast<const float4*>(ep + 2 * n_pad + n);
-                r.x = __builtin_fmaf(r.x, sc.x, sh.x); r.y = __builtin_fmaf(r.y, sc.y, sh.y);
-                r.z = __builtin_fmaf(r.z, sc.z, sh.z); r.w = __builtin_fmaf(r.w, sc.w, sh.w);
+                r = epilogue(acc, bq, p.s1x, p.s2);
+                if (p.post.scale) {
+                    r.x = __builtin_fmaf(r.x, sc.x, sh.x); r.y = __builtin_fmaf(r.y, sc.y, sh.y);
+                    r.z = __builtin_fmaf(r.z, sc.z, sh.z); r.w = __builtin_fmaf(r.w, sc.w, sh.w);
+                }
+            } else {
+                r = epilogue(acc, make_float4(0.f, 0.f, 0.f, 0.f), p.s1x, p.s2);
             }
             if (p.post.relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
             if constexpr (A8) {
@@ -381,17 +389,39 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 4) void k_pw_til
         mfma_step(buf, 1);
     }
 
+    // fused BN/ReLU: this workgroup's BN-channel slices of scale / shift go through the (now free) X tile
+    // in LDS, so the store loop reads them with two ds_read_b128 instead of two global loads per store
+    // (those sat on the critical path of every store: +13 % on these layers)
+    const int n_lo = (int)nb * BN;
+    float* lsc = reinterpret_cast<float*>(xs);   // LDS
+    float* lsh = lsc + BN;
+    if (p.post.scale) {
+        __syncthreads();   // every wave is done with the X tile
+        for (int i = threadIdx.x; i < BN; i += T) {
+            const bool in = n_lo + i < p.N;
+            lsc[i] = in ? p.post.scale[n_lo + i] : 1.f;
+            lsh[i] = in ? p.post.shift[n_lo + i] : 0.f;
+        }
+        __syncthreads();
+    }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int n = (ntile0 + j) * 16 + kq * 4;
         if (n >= p.N) continue;
         const float4 bq = bias_q256(p, n);
-        const PostVec pv = post_load(p.post, n);
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int64_t m = m0 + (wm * MT + i) * 16 + col;
             if (m >= p.M) continue;
-            *reinterpret_cast<float4*>(p.y + (size_t)m * p.N + n) = post_apply_v(epilogue(acc[i][j], bq, p.s1x, p.s2), p.post, pv);
+            float4 r = epilogue(acc[i][j], bq, p.s1x, p.s2);
+            if (p.post.scale) {
+                const float4 sc = *reinterpret_cast<const float4*>(lsc + (n - n_lo));
+                const float4 sh = *reinterpret_cast<const float4*>(lsh + (n - n_lo));
+                r.x = __builtin_fmaf(r.x, sc.x, sh.x); r.y = __builtin_fmaf(r.y, sc.y, sh.y);
+                r.z = __builtin_fmaf(r.z, sc.z, sh.z); r.w = __builtin_fmaf(r.w, sc.w, sh.w);
+            }
+            if (p.post.relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+            *reinterpret_cast<float4*>(p.y + (size_t)m * p.N + n) = r;
         }
     }
 }
