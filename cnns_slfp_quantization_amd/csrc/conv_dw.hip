@@ -118,7 +118,7 @@ __global__ __launch_bounds__(kDwThreads) void k_dw3x3(const float* __restrict__ 
         int lrow = ih * IW * CB + my_c4 * V;                         // LDS offset of the tile row
         const int g_step = (in_step_h * p.W + in_step_w) * p.C, g_wrap = (p.W - IW) * p.C;
         const int l_step = in_step_h * IW * CB, l_wrap = IW * CB;
-        constexpr int U = 8;  // loads kept in flight per thread (a 16x16x32 halo tile = 8 per thread: one batch)
+        constexpr int U = 4;  // loads kept in flight per thread: 4 keeps the kernel at 94 VGPRs (5 waves/SIMD where LDS allows); 8 (one batch per 16x16x32 tile, 114-124 VGPRs) measured 1 % slower in a same-box A/B
         while (pix < n_pix) {
             Vec v[U];
             int dst[U];
