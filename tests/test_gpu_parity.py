@@ -466,6 +466,43 @@ def test_run_to_run_determinism_at_full_size(lib, dev):
             assert torch.equal(y0, y1), (kern, (N, C, H, O, k, s))
 
 
+def test_randomized_geometries_vs_oracle(lib, dev):
+    """Seeded random sweep over geometries (channels incl. odd / non-multiple-of-4 counts, kernel 1..7, stride 1..4,
+    padding, depthwise / dense / small-C_in stems, bias, both precisions, all three MFMA modes): every kernel
+    family and its fallbacks against the oracle, through the C ABI.  What the hand-picked cases might miss."""
+    rng = np.random.default_rng(20261004)
+    kinds = {}
+    for i in range(500):
+        kind = rng.choice(["dw", "pw", "dense", "stem", "any"])
+        k = int(rng.integers(1, 8))
+        s = int(rng.choice([1, 1, 2, 2, 3, 4]))
+        p = int(rng.integers(0, k // 2 + 2))
+        if kind == "dw":
+            C = int(rng.choice([4, 6, 8, 20, 24, 29, 30, 32, 58, 64, 100, 116])); O = C; g = C; k = 3; s = int(rng.choice([1, 2])); p = int(rng.integers(0, 3))
+        elif kind == "pw":
+            C = int(rng.choice([8, 12, 16, 24, 27, 32, 58, 64, 96, 130, 256, 320])); O = int(rng.choice([4, 10, 16, 30, 58, 64, 100, 128, 258, 520])); g = 1; k = 1; p = 0; s = int(rng.choice([1, 1, 2]))
+        elif kind == "dense":
+            C = int(rng.choice([16, 20, 32, 48, 64, 80, 128])); O = int(rng.choice([4, 16, 20, 64, 72, 128, 192, 260])); g = 1; k = int(rng.choice([2, 3, 3, 3, 5])); s = int(rng.choice([1, 1, 2]))
+            p = int(rng.integers(0, k // 2 + 1))
+        elif kind == "stem":
+            C = int(rng.choice([1, 2, 3, 3, 4])); O = int(rng.choice([4, 8, 16, 24, 32, 64, 96])); g = 1; k = int(rng.choice([2, 3, 3, 5, 7, 11])); p = int(rng.integers(0, k // 2 + 1))
+        else:
+            C = int(rng.choice([5, 6, 9, 12, 15, 18])); O = int(rng.choice([3, 6, 9, 12, 18])); g = int(rng.choice([1, 3])) if (C % 3 == 0 and O % 3 == 0) else 1
+        H = int(rng.integers(max(k, 2 * s) + 1, 41))
+        if H + 2 * p < k:
+            continue
+        qbits = int(rng.choice([8, 8, 7]))
+        passes = int(rng.choice([0, 0, 3])) if qbits == 8 else 0
+        bias = bool(rng.integers(0, 2))
+        N = int(rng.integers(1, 4))
+        kern, emax, el2 = _check_against_oracle(lib, dev, N, C, H, O, k, s, p, g, qbits, passes, seed=4000 + i, bias=bias)
+        kinds[kern] = kinds.get(kern, 0) + 1
+    # the sweep must actually reach the families it is meant to cover
+    for fam in ("dw3x3_nhwc", "repad+dw3x3_nhwc", "dense_mfma_f16x1", "dense_mfma_f16x3", "dense_mfma_f16_exact", "stem_small_mfma_f16x1",
+                "stem_mfma_f16x1", "direct_nhwc", "pw_mfma_f16x1", "pw_mfma_f16x3", "pw_mfma_f16_exact", "repad+pw_mfma_f16x1"):
+        assert kinds.get(fam, 0) > 0, (fam, kinds)
+
+
 def test_batch_order_independence(lib, dev):
     """Size-independent property: permuting the images permutes the outputs, bit for bit."""
     Ka, Kw = 0.17, 0.12
