@@ -503,6 +503,27 @@ def test_randomized_geometries_vs_oracle(lib, dev):
         assert kinds.get(fam, 0) > 0, (fam, kinds)
 
 
+def test_randomized_larger_geometries_sampled(lib, dev):
+    """The same idea at sizes where every kernel runs many tiles per image and several images per launch
+    (multi-tile halos, ragged last tiles, XCD-remapped grids): one sampled image per case against the oracle."""
+    rng = np.random.default_rng(77)
+    for i in range(48):
+        kind = i % 4
+        if kind == 0:   # depthwise
+            C = int(rng.choice([32, 58, 64, 116, 128])); O = C; g = C; k = 3; s = int(rng.choice([1, 2])); p = 1
+        elif kind == 1:  # pointwise
+            C = int(rng.choice([32, 58, 128, 256, 512])); O = int(rng.choice([58, 64, 256, 512])); g = 1; k = 1; s = 1; p = 0
+        elif kind == 2:  # dense
+            C = int(rng.choice([16, 64, 128])); O = int(rng.choice([32, 64, 128, 320])); g = 1; k = int(rng.choice([3, 3, 5])); s = int(rng.choice([1, 2])); p = k // 2
+        else:            # stems
+            C = 3; O = int(rng.choice([24, 32, 64, 96])); g = 1; k = int(rng.choice([3, 7, 11])); s = int(rng.choice([1, 2, 4])); p = k // 2
+        H = int(rng.integers(45, 131))
+        N = int(rng.integers(3, 9))
+        qbits = int(rng.choice([8, 8, 7]))
+        passes = int(rng.choice([0, 0, 3])) if qbits == 8 else 0
+        _check_against_oracle(lib, dev, N, C, H, O, k, s, p, g, qbits, passes, seed=6000 + i, images=[N - 1], bias=bool(i & 1))
+
+
 def test_batch_order_independence(lib, dev):
     """Size-independent property: permuting the images permutes the outputs, bit for bit."""
     Ka, Kw = 0.17, 0.12
