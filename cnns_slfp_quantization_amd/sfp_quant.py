@@ -89,31 +89,12 @@ def quantize_act(k):
     return _make_qfn(_lib.FMT_ACT8 if k == 8 else _lib.FMT_SFP7)
 
 
-class _LayeroutSTE(torch.autograd.Function):
-    """SFP<4,4> layer-output quantizer, composite restatement of utils/sfp_quant.py:112-126.
-
-    Quirk kept on purpose: the reference writes `2^(-8)` / `2^(-7)`, which Python parses as
-    integer XOR (= -6 / -5), so its two "subnormal" overrides never fire and only the
-    `>= 248 -> 248` clamp is live; exact zeros therefore come out as NaN (0 * inf) exactly
-    as in the reference."""
-
-    @staticmethod
-    def forward(ctx, x):
-        mag = x.abs()
-        e = torch.floor(torch.log2(mag))
-        scale = torch.pow(2, e)
-        out = torch.round(mag / scale * 16) / 16 * scale
-        out = torch.where(mag >= 248, torch.full_like(out, 248.0), out)
-        return torch.sign(x) * out
-
-    @staticmethod
-    def backward(ctx, g):
-        return g.clone()
-
-
 class _LayeroutHip(torch.autograd.Function):
-    """The same quantizer as ONE HIP pass (slfp_quantize_layerout_f32), bit-identical to the
-    reference (tests/golden: all denormals + sampled binades); STE backward (:129-132)."""
+    """SFP<4,4> layer-output quantizer (utils/sfp_quant.py:112-126) as ONE HIP pass
+    (slfp_quantize_layerout_f32), bit-identical to the reference including its quirks (tests/golden: all
+    denormals + sampled binades): the reference writes `2^(-8)` / `2^(-7)`, which Python parses as integer
+    XOR (= -6 / -5), so its two "subnormal" overrides never fire, only the `>= 248 -> 248` clamp is live and
+    exact zeros come out as NaN (0 * inf).  STE backward (:129-132)."""
 
     @staticmethod
     def forward(ctx, x):
@@ -131,10 +112,8 @@ class _LayeroutHip(torch.autograd.Function):
 
 
 def _layerout_dispatch(x):
-    # ROCm float32 tensors take the HIP kernel; anything else the plain-PyTorch mirror above
-    if x.is_cuda and x.dtype == torch.float32:
-        return _LayeroutHip.apply(x)
-    return _LayeroutSTE.apply(x)
+    _require_gpu_f32(x, "quantize_layerout")   # no CPU compute path: the CPU restatement lives in oracle/ (tests only)
+    return _LayeroutHip.apply(x)
 
 
 def quantize_layerout(k):

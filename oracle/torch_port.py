@@ -71,3 +71,15 @@ def linear_q(x, weight, bias, Ka, Kw, bits):
     wq = fake_quant(weight / Kw, bits, "weight")
     bq = None if bias is None else bias / Kw / Ka
     return F.linear(xq, wq, bq) * Kw * Ka
+
+
+def layerout(x):
+    """quantize_layerout(k <= 8).forward (utils/sfp_quant.py:112-126), the reference's op sequence with its
+    quirks: `2^(-8)` / `2^(-7)` are integer XORs there (= -6 / -5), so the two "subnormal" overrides never
+    fire, only the `>= 248 -> 248` clamp is live and exact zeros come out as NaN (0 * inf)."""
+    mag = x.abs()
+    e = torch.floor(torch.log2(mag))
+    scale = torch.pow(2, e)
+    out = torch.round(mag / scale * 16) / 16 * scale
+    out = torch.where(mag >= 248, torch.full_like(out, 248.0), out)
+    return torch.sign(x) * out

@@ -153,13 +153,19 @@ def test_no_cpu_compute_path_and_qbit32_passthrough():
     assert cf.quantize_act(32)(x) is x and cf.layerout_quantize_func(32)(x) is x
 
 
-def test_layerout_composite_keeps_reference_quirks():
+def test_layerout_restatement_keeps_reference_quirks_and_product_has_no_cpu_path():
+    from oracle import torch_port
+    from oracle import slfp_oracle as so
     from utils.sfp_quant import layerout_quantize_func
-    q = layerout_quantize_func(8)
-    y = q(torch.tensor([0.3, 1.03, 300.0, -500.0, 0.0]))
+    x = torch.tensor([0.3, 1.03, 300.0, -500.0, 0.0])
+    y = torch_port.layerout(x)                       # the reference's op sequence (test infrastructure)
     assert y[0].item() == pytest.approx(0.296875) and y[1].item() == pytest.approx(1.0)
     assert y[2].item() == 248.0 and y[3].item() == -248.0
     assert torch.isnan(y[4])  # exact zero -> NaN in the reference too (2^(-8) is XOR there)
+    yo = so.layerout(x.numpy())                      # the integer restatement agrees
+    assert np.array_equal(np.isnan(yo), np.isnan(y.numpy())) and np.array_equal(yo[:4], y.numpy()[:4])
+    with pytest.raises(RuntimeError):                # the product refuses CPU tensors (no CPU compute path)
+        layerout_quantize_func(8)(x)
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/nets_cifar"), reason="reference not mounted (GPU box)")
