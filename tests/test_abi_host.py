@@ -231,3 +231,17 @@ def test_fuse_bn_relu_host_logic():
     m.train()
     with pytest.raises(RuntimeError):
         fusion.fold_bn(m[1])  # training-mode BN cannot be folded
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: only tests/, __graft_entry__ (build / smoke) and bench.py's cpu_baseline leg
+    may import it.  A product path that routed through it would void every parity claim."""
+    import glob
+    offenders = []
+    for path in glob.glob(os.path.join(ROOT, "cnns_slfp_quantization_amd", "*.py")) + glob.glob(os.path.join(ROOT, "utils", "*.py")):
+        for line in open(path):
+            if re.match(r"\s*(from|import)\s+oracle\b", line):
+                offenders.append((path, line.strip()))
+    assert not offenders, offenders
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    assert bench.count("from oracle") == 1 and "def cpu_baseline" in bench.split("from oracle")[0].rsplit("\ndef ", 1)[-1]
