@@ -16,7 +16,8 @@
 // that the 8 pixels a wave reads for one tap are contiguous in LDS (no bank conflicts).
 // Tried and dropped (same-box A/B, profiles/ab_compare.sh): keeping the 16-entry encode table in a VGPR and
 // reading it with ds_bpermute so that the exactly-32-KiB 16x16x32 tile lets five workgroups share a CU
-// instead of four: 2.7 % slower (the crossbar lookup costs more than the fifth workgroup brings).
+// instead of four: 2.7 % slower (the crossbar lookup costs more than the fifth workgroup brings); unrolling the
+// compute loop by two (18 tap reads in flight per thread): 3 % slower at the same 94 VGPRs.
 // rocprof (profiles/r01a) showed HBM traffic already ideal (halo re-reads hit L2) and the
 // kernel VALU-bound, so all index arithmetic is incremental (no runtime div/mod in loops).
 #include "slfp_device.hpp"
