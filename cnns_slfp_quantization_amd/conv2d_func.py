@@ -136,7 +136,7 @@ def _hip_conv2d(mod, x, weight, bias):
             b = bias.detach()
             b = b if b.is_contiguous() else b.contiguous()
         xq = torch.empty_like(x) if options.eager_stash else None
-        post = getattr(mod, "_post", None)  # (scale, shift, relu) set by fusion.fuse_bn_relu: eval-BN + ReLU in the epilogue
+        post = getattr(mod, "_post", None)  # (scale, shift, flags) set by fusion.fuse_bn_relu: eval-BN (+ layerout) + ReLU in the epilogue
         ps = psh = None
         relu = 0
         if post is not None:
@@ -147,7 +147,7 @@ def _hip_conv2d(mod, x, weight, bias):
         _lib.check(L.slfp_conv2d_fwd_post(ctypes.byref(d), x.data_ptr(), blob.data_ptr(),
                                           b.data_ptr() if b is not None else None,
                                           ps.data_ptr() if ps is not None else None,
-                                          psh.data_ptr() if psh is not None else None, int(bool(relu)), y.data_ptr(),
+                                          psh.data_ptr() if psh is not None else None, int(relu), y.data_ptr(),
                                           xq.data_ptr() if xq is not None else None,
                                           ws.data_ptr() if ws is not None else None, _stream_handle(x)))
     mod._last_kernel = L.slfp_conv2d_kernel_name(ctypes.byref(d)).decode()
@@ -192,10 +192,10 @@ def _apply_post_composite(out, post):
     """The fused epilogue written with stock ATen ops (q_bit == 32 passthrough only)."""
     if post is None:
         return out
-    scale, shift, relu = post
+    scale, shift, flags = post   # flags: 1 = ReLU (the layer-output quantizer is never fused onto a q_bit 32 conv)
     if scale is not None:
         out = out * scale.to(out.device).view(1, -1, 1, 1) + shift.to(out.device).view(1, -1, 1, 1)
-    return torch.relu(out) if relu else out
+    return torch.relu(out) if (int(flags) & 1) else out
 
 
 def _conv_class(q_bit, Kw, Ka, bias_default, scaled_bias):

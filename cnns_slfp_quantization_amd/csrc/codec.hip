@@ -96,23 +96,7 @@ __global__ __launch_bounds__(kThreads) void k_decode(const uint8_t* __restrict__
         y[i] = __uint_as_float(decode_bits<FMT>(code[i], ext, sT));
 }
 
-// quantize_layerout(k <= 8).forward (utils/sfp_quant.py:108-127): SFP<4,4> layer-output quantizer.
-// The reference's `2^(-8)` is integer XOR, so only three things are live: RNE to 5 significant
-// bits at every exponent (denormals included), the >= 248 clamp, and NaN for an exact zero.
-__device__ __forceinline__ uint32_t layerout_bits(uint32_t u) {
-    const uint32_t a = u & 0x7FFFFFFFu, s = u & 0x80000000u;
-    uint32_t v = (a + 0x3FFFFu + ((a >> 19) & 1u)) & 0xFFF80000u;
-    if (a < 0x00800000u && a != 0u) {  // denormal: keep 5 significant bits (rare path)
-        const int p = 31 - __clz((int)a);
-        const int sh = p > 4 ? p - 4 : 0;
-        v = sh > 0 ? ((a + ((1u << (sh - 1)) - 1u) + ((a >> sh) & 1u)) >> sh) << sh : a;
-    }
-    v = a >= 0x43780000u ? 0x43780000u : v;  // >= 248 -> 248
-    v |= s;
-    v = (a == 0u || a > 0x7F800000u) ? kBitsQNaN : v;  // 0 * inf in the reference; NaN in -> NaN out
-    return v;
-}
-
+// quantize_layerout: layerout_bits() lives in slfp_device.hpp (the conv epilogues can fuse it too)
 __global__ __launch_bounds__(kThreads) void k_layerout(const float* __restrict__ x, float* __restrict__ y, size_t n, int vec_ok) {
     const size_t nvec = vec_ok ? n / 4 : 0;
     const size_t stride = (size_t)gridDim.x * kThreads;

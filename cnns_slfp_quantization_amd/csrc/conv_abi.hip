@@ -310,7 +310,11 @@ int slfp_conv2d_fwd_post(const slfp_conv2d_desc* d, const float* x, const void* 
         return fail(SLFP_ERR_BAD_ARG, "slfp_conv2d_fwd_post: post_scale and post_shift must be given together");
     if (post_scale && (!aligned16(post_scale) || !aligned16(post_shift)))
         return fail(SLFP_ERR_ALIGNMENT, "slfp_conv2d_fwd_post: post_scale / post_shift must be 16-byte aligned");
-    const PostOp post{post_scale, post_shift, relu ? 1 : 0};
+    if ((relu & ~(SLFP_POST_RELU | SLFP_POST_LAYEROUT)) != 0)
+        return fail(SLFP_ERR_BAD_ARG, "slfp_conv2d_fwd_post: unknown flag bits in `relu`");
+    if ((relu & SLFP_POST_LAYEROUT) && !post_scale)
+        return fail(SLFP_ERR_BAD_ARG, "slfp_conv2d_fwd_post: SLFP_POST_LAYEROUT needs post_scale / post_shift");
+    const PostOp post{post_scale, post_shift, (relu & SLFP_POST_RELU) ? 1 : 0, (relu & SLFP_POST_LAYEROUT) ? 1 : 0};
     if (!aligned16(x) || !aligned16(y) || !aligned16(wprep) || (bias && !aligned16(bias)))
         return fail(SLFP_ERR_ALIGNMENT, "slfp_conv2d_fwd: x, y, wprep and bias must be 16-byte aligned");
     hipStream_t st = as_stream(stream);
@@ -360,7 +364,7 @@ int slfp_conv2d_fwd_post(const slfp_conv2d_desc* d, const float* x, const void* 
             if (rc != SLFP_OK) return rc;
             vec[i] = vp;
         }
-        const PostOp post2{vec[1], vec[2], relu ? 1 : 0};
+        const PostOp post2{vec[1], vec[2], post.relu, post.layerout};
         if (p.family == kDw3x3) rc = launch_dw3x3(d2, p, xin, reinterpret_cast<const float*>(wprep), vec[0], post2, yout, st);
         else rc = launch_pointwise(d2, p, xin, wprep, vec[0], post2, yout, st);
         if (rc != SLFP_OK) return rc;
@@ -428,7 +432,7 @@ int slfp_linear_fwd_prepared(const float* x, const void* wprep, const float* bia
         return fail(SLFP_ERR_ALIGNMENT, "slfp_linear_fwd: pointers must be 16-byte aligned");
     p.s1 = kw_scale;
     p.s2 = ka;
-    const PostOp none{nullptr, nullptr, 0};
+    const PostOp none{nullptr, nullptr, 0, 0};
     hipStream_t st = as_stream(stream);
     if (p.family == kPointwise) return launch_pointwise(d, p, x, wprep, bias, none, y, st);
     return launch_direct(d, p, x, reinterpret_cast<const float*>(wprep), bias, none, y, st);

@@ -49,7 +49,9 @@ struct alignas(V * 4) DwVec {
 
 // CBT / IWT > 0: channel-group width and input-tile width known at compile time (the MobileNetV1
 // tiles): every LDS offset becomes an immediate and the row-wrap arithmetic folds away.
-template <int FMT, int S, int CBT, int IWT, int V = 4>
+// LO: the fused SFP<4,4> layer-output quantizer (PostOp::layerout) is compiled in; kept out of the default
+// instantiations, whose store loop it slowed by 1 % (same-box A/B) even when not taken.
+template <int FMT, int S, int CBT, int IWT, int V = 4, bool LO = false>
 __global__ __launch_bounds__(kDwThreads) void k_dw3x3(const float* __restrict__ x, const float* __restrict__ wq,
                                                       const float* __restrict__ bias, float* __restrict__ y,
                                                       const DwParams p) {
@@ -191,7 +193,10 @@ __global__ __launch_bounds__(kDwThreads) void k_dw3x3(const float* __restrict__ 
 #pragma unroll
                 for (int e = 0; e < V; ++e) {
                     float t = (acc.v[e] * p.ka) * p.kw;
-                    if (p.post.scale) t = __builtin_fmaf(t, psc.v[e], psh.v[e]);
+                    if (p.post.scale) {
+                        t = __builtin_fmaf(t, psc.v[e], psh.v[e]);
+                        if constexpr (LO) t = layerout1(t);
+                    }
                     if (p.post.relu) t = fmaxf(t, 0.f);
                     r.v[e] = t;
                 }
@@ -251,9 +256,17 @@ int launch_dw3x3(const slfp_conv2d_desc& d, const ConvPlan& plan, const float* x
     const bool a8 = plan.fmt_act == kFmtAct8;
 #define SLFP_DW_LAUNCH(FMT, SS, CBT, IWT, VV) \
     hipLaunchKernelGGL((k_dw3x3<FMT, SS, CBT, IWT, VV>), dim3(p.nblocks), dim3(kDwThreads), lds, stream, x, wq9c, bias, y, p)
+#define SLFP_DW_LAUNCH_LO(FMT, SS, VV) \
+    hipLaunchKernelGGL((k_dw3x3<FMT, SS, 0, 0, VV, true>), dim3(p.nblocks), dim3(kDwThreads), lds, stream, x, wq9c, bias, y, p)
 #define SLFP_DW_BY_FMT(SS, CBT, IWT, VV) \
     do { if (a8) SLFP_DW_LAUNCH(kFmtAct8, SS, CBT, IWT, VV); else SLFP_DW_LAUNCH(kFmtSfp7, SS, CBT, IWT, VV); } while (0)
-    if (v2) {
+    if (p.post.layerout && p.post.scale) {   // fused layer-output quantizer: the generic-geometry instantiations only
+        if (a8) { if (S == 1) { if (v2) SLFP_DW_LAUNCH_LO(kFmtAct8, 1, 2); else SLFP_DW_LAUNCH_LO(kFmtAct8, 1, 4); }
+                  else        { if (v2) SLFP_DW_LAUNCH_LO(kFmtAct8, 2, 2); else SLFP_DW_LAUNCH_LO(kFmtAct8, 2, 4); } }
+        else    { if (S == 1) { if (v2) SLFP_DW_LAUNCH_LO(kFmtSfp7, 1, 2); else SLFP_DW_LAUNCH_LO(kFmtSfp7, 1, 4); }
+                  else        { if (v2) SLFP_DW_LAUNCH_LO(kFmtSfp7, 2, 2); else SLFP_DW_LAUNCH_LO(kFmtSfp7, 2, 4); } }
+    }
+    else if (v2) {
         if (S == 1 && p.CB == 32 && p.IW == 16) SLFP_DW_BY_FMT(1, 32, 16, 2);
         else if (S == 1) SLFP_DW_BY_FMT(1, 0, 0, 2);
         else SLFP_DW_BY_FMT(2, 0, 0, 2);
@@ -264,6 +277,7 @@ int launch_dw3x3(const slfp_conv2d_desc& d, const ConvPlan& plan, const float* x
     else if (S == 1) SLFP_DW_BY_FMT(1, 0, 0, 4);
     else SLFP_DW_BY_FMT(2, 0, 0, 4);
 #undef SLFP_DW_BY_FMT
+#undef SLFP_DW_LAUNCH_LO
 #undef SLFP_DW_LAUNCH
     return check_launch("slfp dw3x3 kernel");
 }

@@ -230,6 +230,7 @@ __global__ __launch_bounds__(kStreamThreads) void k_pw_stream(const PwParams p) 
                 if (p.post.scale) {
                     r.x = __builtin_fmaf(r.x, sc.x, sh.x); r.y = __builtin_fmaf(r.y, sc.y, sh.y);
                     r.z = __builtin_fmaf(r.z, sc.z, sh.z); r.w = __builtin_fmaf(r.w, sc.w, sh.w);
+                    if (p.post.layerout) r = layerout4(r);
                 }
             } else {
                 r = epilogue(acc, make_float4(0.f, 0.f, 0.f, 0.f), p.s1x, p.s2);
@@ -419,6 +420,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 4) void k_pw_til
                 const float4 sh = *reinterpret_cast<const float4*>(lsh + (n - n_lo));
                 r.x = __builtin_fmaf(r.x, sc.x, sh.x); r.y = __builtin_fmaf(r.y, sc.y, sh.y);
                 r.z = __builtin_fmaf(r.z, sc.z, sh.z); r.w = __builtin_fmaf(r.w, sc.w, sh.w);
+                if (p.post.layerout) r = layerout4(r);
             }
             if (p.post.relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
             *reinterpret_cast<float4*>(p.y + (size_t)m * p.N + n) = r;

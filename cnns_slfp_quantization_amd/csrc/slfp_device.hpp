@@ -207,7 +207,30 @@ struct PostOp {
     const float* scale;
     const float* shift;
     int relu;
+    int layerout;  // only with scale/shift: SFP<4,4> layer-output quantizer between the affine and the ReLU
 };
+
+// quantize_layerout(k <= 8).forward (utils/sfp_quant.py:108-127): SFP<4,4> layer-output quantizer.
+// The reference's `2^(-8)` is integer XOR, so only three things are live: RNE to 5 significant
+// bits at every exponent (denormals included), the >= 248 clamp, and NaN for an exact zero.
+__device__ __forceinline__ uint32_t layerout_bits(uint32_t u) {
+    const uint32_t a = u & 0x7FFFFFFFu, s = u & 0x80000000u;
+    uint32_t v = (a + 0x3FFFFu + ((a >> 19) & 1u)) & 0xFFF80000u;
+    if (a < 0x00800000u && a != 0u) {  // denormal: keep 5 significant bits (rare path)
+        const int p = 31 - __clz((int)a);
+        const int sh = p > 4 ? p - 4 : 0;
+        v = sh > 0 ? ((a + ((1u << (sh - 1)) - 1u) + ((a >> sh) & 1u)) >> sh) << sh : a;
+    }
+    v = a >= 0x43780000u ? 0x43780000u : v;  // >= 248 -> 248
+    v |= s;
+    v = (a == 0u || a > 0x7F800000u) ? kBitsQNaN : v;  // 0 * inf in the reference; NaN in -> NaN out
+    return v;
+}
+
+__device__ __forceinline__ float layerout1(float r) { return __uint_as_float(layerout_bits(__float_as_uint(r))); }
+__device__ __forceinline__ float4 layerout4(float4 r) {
+    return make_float4(layerout1(r.x), layerout1(r.y), layerout1(r.z), layerout1(r.w));
+}
 
 __device__ __forceinline__ float4 post_apply(float4 r, const PostOp po, int c) {
     if (po.scale) {
@@ -242,13 +265,17 @@ __device__ __forceinline__ float4 post_apply_v(float4 r, const PostOp po, const 
     if (po.scale) {
         r.x = __builtin_fmaf(r.x, v.sc.x, v.sh.x); r.y = __builtin_fmaf(r.y, v.sc.y, v.sh.y);
         r.z = __builtin_fmaf(r.z, v.sc.z, v.sh.z); r.w = __builtin_fmaf(r.w, v.sc.w, v.sh.w);
+        if (po.layerout) r = layerout4(r);
     }
     if (po.relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
     return r;
 }
 
 __device__ __forceinline__ float post_apply1(float r, const PostOp po, int c) {
-    if (po.scale) r = __builtin_fmaf(r, po.scale[c], po.shift[c]);
+    if (po.scale) {
+        r = __builtin_fmaf(r, po.scale[c], po.shift[c]);
+        if (po.layerout) r = layerout1(r);
+    }
     if (po.relu) r = fmaxf(r, 0.f);
     return r;
 }

@@ -30,24 +30,34 @@ def fold_bn(bn):
     return scale.float().contiguous(), shift.float().contiguous()
 
 
-def fuse_pair(conv, bn=None, relu=False):
-    """Attach bn (eval-mode nn.BatchNorm2d or None) and an optional ReLU to `conv`'s epilogue."""
+def fuse_pair(conv, bn=None, relu=False, layerout=False):
+    """Attach bn (eval-mode nn.BatchNorm2d or None), an optional SFP<4,4> layer-output quantizer
+    (utils/sfp_quant.py:105-133; needs bn) and an optional ReLU to `conv`'s epilogue, in that order."""
     if not _is_conv_q(conv):
         raise TypeError("fuse_pair: conv must be a Conv2d_Q module of this package")
+    if layerout and bn is None:
+        raise ValueError("fuse_pair: the layer-output quantizer is fused only together with a BatchNorm2d")
+    flags = (1 if relu else 0) | (2 if layerout else 0)   # SLFP_POST_RELU | SLFP_POST_LAYEROUT
     if bn is not None:
         if bn.num_features != conv.out_channels:
             raise ValueError("fuse_pair: BatchNorm2d width does not match the conv's out_channels")
         scale, shift = fold_bn(bn)
         dev = conv.weight.device
-        conv._post = (scale.to(dev), shift.to(dev), bool(relu))
+        conv._post = (scale.to(dev), shift.to(dev), flags)
     else:
-        conv._post = (None, None, bool(relu))
+        conv._post = (None, None, flags)
     return conv
 
 
+def _is_layerout(m):
+    """layerout_quantize_func(q_bit <= 8): the SFP<4,4> quantizer module of the `*_swish` / `*_gelu` / ShuffleNetV2 nets."""
+    return type(m).__name__ == "layerout_quantize_func" and getattr(m, "q_bit", 32) in (8, 7)
+
+
 def fuse_bn_relu(model):
-    """Fuse every [Conv2d_Q, BatchNorm2d(eval), (ReLU)] run found in nn.Sequential containers.
-    Returns the number of fused convolutions."""
+    """Fuse every [Conv2d_Q, BatchNorm2d(eval), (layerout_quantize_func), (ReLU)] run found in nn.Sequential
+    containers (nets_imgnet/mobilenetv1.py:24-41; nets_cifar/mobilenetv1.py:196-231 for the layerout form; a
+    Swish / GELU after the quantizer stays a module).  Returns the number of fused convolutions."""
     n = 0
     for seq in [m for m in model.modules() if isinstance(m, nn.Sequential)]:
         names = list(seq._modules.keys())
@@ -59,14 +69,17 @@ def fuse_bn_relu(model):
                 ok = (isinstance(bn, nn.BatchNorm2d) and not bn.training and bn.num_features == conv.out_channels
                       and (conv.bias is None or getattr(conv, "_scaled_bias", False)))
                 if ok:
-                    relu = i + 2 < len(names) and isinstance(seq._modules[names[i + 2]], nn.ReLU)
-                    fuse_pair(conv, bn, relu)
-                    conv._fused_modules = (bn, seq._modules[names[i + 2]] if relu else None)
-                    seq._modules[names[i + 1]] = nn.Identity()
-                    if relu:
-                        seq._modules[names[i + 2]] = nn.Identity()
+                    j = i + 2
+                    lo = (j < len(names) and _is_layerout(seq._modules[names[j]]) and conv.q_bit in (8, 7))
+                    j += 1 if lo else 0
+                    relu = j < len(names) and isinstance(seq._modules[names[j]], nn.ReLU)
+                    j += 1 if relu else 0
+                    fuse_pair(conv, bn, relu, lo)
+                    conv._fused_modules = [(names[k], seq._modules[names[k]]) for k in range(i + 1, j)]
+                    for k in range(i + 1, j):
+                        seq._modules[names[k]] = nn.Identity()
                     n += 1
-                    i += 3 if relu else 2
+                    i = j
                     continue
             i += 1
     return n
@@ -80,10 +93,8 @@ def unfuse(model):
         for i, name in enumerate(names):
             conv = seq._modules[name]
             if _is_conv_q(conv) and conv._post is not None and hasattr(conv, "_fused_modules"):
-                bn, relu = conv._fused_modules
-                seq._modules[names[i + 1]] = bn
-                if relu is not None:
-                    seq._modules[names[i + 2]] = relu
+                for key, mod in conv._fused_modules:
+                    seq._modules[key] = mod
                 conv._post = None
                 del conv._fused_modules
                 n += 1

@@ -127,6 +127,11 @@ int slfp_conv2d_fwd(const slfp_conv2d_desc* d, const float* x, const void* wprep
  * post_scale = gamma / sqrt(running_var + eps), post_shift = beta - running_mean * post_scale,
  * float32[C_out], 16-byte aligned; both NULL = no affine.  The conv result itself keeps the
  * reference's (out * Ka) * Kw roundings; the affine is one fused multiply-add on top. */
+#define SLFP_POST_RELU 1      /* `relu` argument of slfp_conv2d_fwd_post: max(., 0) last                         */
+#define SLFP_POST_LAYEROUT 2  /* SFP<4,4> layer-output quantizer (slfp_quantize_layerout_f32) between the affine
+                                 and the ReLU: the [Conv2d_Q, BatchNorm2d, layerout_quantize_func, ReLU] blocks of
+                                 MobileNetV1_swish / VGG16_gelu / ShuffleNetV2 (nets_cifar/mobilenetv1.py:196-231);
+                                 needs post_scale / post_shift                                                  */
 int slfp_conv2d_fwd_post(const slfp_conv2d_desc* d, const float* x, const void* wprep, const float* bias,
                          const float* post_scale, const float* post_shift, int relu, float* y,
                          float* input_q, void* workspace, void* stream);

@@ -223,7 +223,7 @@ def test_fuse_bn_relu_host_logic():
         y0 = m(x)
         assert fusion.fuse_bn_relu(m) == 3
         assert [type(c).__name__ for c in m] == ["Conv2d_Q", "Identity", "Identity", "Conv2d_Q", "Identity", "Conv2d_Q", "Identity", "Identity"]
-        assert m[0]._post[2] is True and m[3]._post[2] is False
+        assert m[0]._post[2] == 1 and m[3]._post[2] == 0   # flags: SLFP_POST_RELU
         y1 = m(x)
         assert torch.allclose(y0, y1, rtol=1e-5, atol=1e-5)
         assert fusion.unfuse(m) == 3 and isinstance(m[1], nn.BatchNorm2d) and isinstance(m[6], nn.BatchNorm2d) and m[0]._post is None

@@ -723,6 +723,53 @@ def test_fused_bn_relu_epilogue_matches_stock_modules(dev):
         cf.options.mfma_passes = 0
 
 
+def test_fused_layerout_quantizer_epilogue(dev):
+    """[Conv2d_Q, BatchNorm2d, layerout_quantize_func, ReLU] (nets_cifar/mobilenetv1.py:196-231) folded into the conv
+    epilogue (SLFP_POST_LAYEROUT).  Bit-exact against the SAME folded affine followed by the standalone
+    SFP<4,4> kernel and ReLU; against the stock modules only the rare quantizer-boundary flips that folding
+    BN into one fma causes may differ (each by one quantization step)."""
+    import utils.conv2d_func as cf
+    import utils.sfp_quant as sq
+    from cnns_slfp_quantization_amd import fusion
+    Ka, Kw = np.float64(0.17), np.float64(0.12)
+    C, Cb = cf.conv2d_Q(8, Kw, Ka), cf.conv2d_Q_bias(8, Kw, Ka)
+    g = torch.Generator(device="cpu").manual_seed(21)
+    cases = [(C(3, 32, 3, Kw, Ka, 2, 1), 3, 33), (C(64, 64, 3, Kw, Ka, 1, 1, groups=64), 64, 20), (C(64, 128, 1, Kw, Ka), 64, 14),
+             (C(256, 512, 1, Kw, Ka), 256, 9), (Cb(16, 32, 3, Kw, Ka, 1, 1), 16, 12), (C(3, 64, 7, Kw, Ka, 2, 3), 3, 40),
+             (C(3, 24, 3, Kw, Ka, 1, 1), 3, 30), (C(58, 58, 3, Kw, Ka, 1, 1, groups=58), 58, 13), (C(24, 58, 1, Kw, Ka), 24, 13),
+             (C(6, 9, 3, Kw, Ka, 1, 1, groups=3), 6, 11)]
+    for conv, cin, hw in cases:
+        seq = torch.nn.Sequential(conv, torch.nn.BatchNorm2d(conv.out_channels), sq.layerout_quantize_func(8),
+                                  torch.nn.ReLU(inplace=True)).to(dev).eval()
+        bn = seq[1]
+        with torch.no_grad():
+            conv.weight.copy_((torch.randn(conv.weight.shape, generator=g) * 0.4).to(dev))
+            bn.running_mean.copy_((torch.randn(bn.num_features, generator=g) * 0.3).to(dev))
+            bn.running_var.copy_((torch.rand(bn.num_features, generator=g) + 0.5).to(dev))
+            bn.weight.copy_((torch.rand(bn.num_features, generator=g) + 0.5).to(dev))
+            bn.bias.copy_((torch.randn(bn.num_features, generator=g) * 0.2).to(dev))
+            x = (torch.randn((3, cin, hw, hw), generator=g) * 0.8).to(dev).contiguous(memory_format=torch.channels_last)
+            y_stock = seq(x)
+            # (a) folded affine only, then the standalone quantizer + ReLU
+            fusion.fuse_pair(conv, bn, relu=False, layerout=False)
+            y_ref = torch.relu(sq.quantize_layerout(8)(conv(x)))
+            conv._post = None
+            # (b) everything in the epilogue
+            assert fusion.fuse_bn_relu(seq) == 1
+            assert [type(m).__name__ for m in seq][1:] == ["Identity", "Identity", "Identity"] and conv._post[2] == 3
+            y_fused = seq(x)
+            assert same_bits(y_fused.cpu().numpy(), y_ref.cpu().numpy()), conv._last_kernel
+            a, b = y_fused.cpu().numpy(), y_stock.cpu().numpy()
+            both = ~(np.isnan(a) | np.isnan(b))
+            same = (a == b) | (np.isnan(a) & np.isnan(b))
+            assert same.mean() >= 0.999, (conv._last_kernel, same.mean())
+            d = np.abs(a - b)[both & ~same]
+            ref = np.maximum(np.abs(a), np.abs(b))[both & ~same]
+            assert d.size == 0 or np.all(d <= ref * 0.07 + 1e-6), conv._last_kernel   # one SFP<4,4> step (2^-4) at most
+            assert fusion.unfuse(seq) == 1 and type(seq[2]).__name__ == "layerout_quantize_func"
+            assert same_bits(seq(x).cpu().numpy(), y_stock.cpu().numpy())
+
+
 def test_layerout_quantizer_and_absmax(lib, dev, codec_golden):
     """Next-row components on the device: quantize_layerout (SFP<4,4>, bit-exact vs the reference's
     golden incl. denormals / NaN-for-zero) and the calibration statistic max|x| (wave shuffle reduction)."""
