@@ -270,11 +270,19 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     L = _lib.load()  # raises if the HIP extension is missing: no fallback
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal knobs (1-GPU box): SLFP_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and SLFP_BENCH_BACKEND=gloo
+    # replaces RCCL (which refuses two ranks on one device), so the N > 1 control flow can be exercised
+    share = os.environ.get("SLFP_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("SLFP_BENCH_BACKEND", "nccl")
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
 
     specs = layer_specs.conv_layers(args.net)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
