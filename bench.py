@@ -101,7 +101,7 @@ class Layer:
             _lib.check(rc)
 
 
-FAMILY_KERNELS = {"dw3x3_nhwc": ("k_dw3x3",), "stem_nhwc": ("k_stem",), "direct_nhwc": ("k_direct",),
+FAMILY_KERNELS = {"dw3x3_nhwc": ("k_dw3x3",), "stem_nhwc": ("k_stem", "k_stem_fixed"), "direct_nhwc": ("k_direct",),
                   "pw_mfma_f16x1": ("k_pw_stream", "k_pw_tiled"), "pw_mfma_f16x3": ("k_pw_stream", "k_pw_tiled"),
                   "pw_mfma_f16_exact": ("k_pw_stream", "k_pw_tiled"),
                   "dense_mfma_f16x1": ("k_dense_mfma", "k_dense_encode"), "dense_mfma_f16x3": ("k_dense_mfma", "k_dense_encode"), "dense_mfma_f16_exact": ("k_dense_mfma", "k_dense_encode"),
