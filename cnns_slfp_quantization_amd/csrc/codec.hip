@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include "slfp_device.hpp"
+#include "slfp_enc.hpp"
 #include "slfp_host.hpp"
 
 namespace slfp {
@@ -72,6 +73,31 @@ __global__ __launch_bounds__(kThreads) void k_codec(const float* __restrict__ x,
         } else {
             reinterpret_cast<uint8_t*>(out)[i] = (uint8_t)quant_code<FMT>(u, __float_as_uint(xi), ext);
         }
+    }
+}
+
+// y = Q(x/scale) float32 through the threshold table (slfp_enc.hpp): 7 VALU instructions per element instead
+// of 22.  `+ 0.0f` turns the table form's -0 (x = -0, or a negative x whose quotient underflows) into the
+// reference's +0 (torch.sign(-0) == 0) and changes nothing else.
+__global__ __launch_bounds__(kThreads) void k_quantize_tab(const float* __restrict__ x, float* __restrict__ y, size_t n,
+                                                           const EncArgs t, int vec_ok) {
+    __shared__ __attribute__((aligned(16))) uint2 sE[kEncEntries + 1];
+    enc_fill<kThreads>(sE, t);
+    __syncthreads();
+    const unsigned char* tb = reinterpret_cast<const unsigned char*>(sE);
+    const float r1 = t.r1, lo = t.lo, hi = t.hi;
+    const size_t nvec = vec_ok ? n / 4 : 0;
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += stride) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        float4 r = enc4_f32(v, r1, lo, hi, tb);
+        r.x += 0.0f; r.y += 0.0f; r.z += 0.0f; r.w += 0.0f;
+        reinterpret_cast<float4*>(y)[i] = r;
+    }
+    for (size_t i = nvec * 4 + (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+        const float xi = x[i];
+        float r = enc_f32(xi, r1, lo, hi, tb) + 0.0f;
+        y[i] = xi != xi ? __uint_as_float(kBitsQNaN) : r;
     }
 }
 
@@ -144,6 +170,13 @@ static int launch_codec(const float* x, void* out, size_t n, float scale, int fm
     const int f = fmt & kFmtMask, ext = (fmt & kFmtExt) ? 1 : 0;
     const int vec_ok = aligned16(x) && ((reinterpret_cast<uintptr_t>(out) & (MODE == 0 ? 15u : 3u)) == 0);
     const int g = grid_for(n);
+    if (MODE == 0 && (f == kFmtAct8 || f == kFmtSfp7)) {
+        const EncArgs* t = act_table(scale, f, kEncF32);
+        if (t) {
+            hipLaunchKernelGGL(k_quantize_tab, dim3(g), dim3(kThreads), 0, st, x, reinterpret_cast<float*>(out), n, *t, vec_ok);
+            return check_launch("slfp codec kernel (threshold table)");
+        }
+    }
     const ScaleDiv sd = make_scale_div(scale);
     switch (f) {
         case kFmtAct8: hipLaunchKernelGGL((k_codec<kFmtAct8, MODE>), dim3(g), dim3(kThreads), 0, st, x, out, n, sd, ext, vec_ok); break;

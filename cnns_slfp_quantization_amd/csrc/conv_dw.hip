@@ -38,6 +38,7 @@ struct DwParams {
     float ka, kw;
     PostOp post;
     uint32_t nblocks;
+    EncArgs enc;                 // threshold table of QA(x / Ka) (TAB kernels; slfp_enc.hpp)
 };
 
 // V floats per lane: 4 (16-byte accesses) or 2 (channel counts that are even but not a multiple of 4,
@@ -51,16 +52,20 @@ struct alignas(V * 4) DwVec {
 // tiles): every LDS offset becomes an immediate and the row-wrap arithmetic folds away.
 // LO: the fused SFP<4,4> layer-output quantizer (PostOp::layerout) is compiled in; kept out of the default
 // instantiations, whose store loop it slowed by 1 % (same-box A/B) even when not taken.
-template <int FMT, int S, int CBT, int IWT, int V = 4, bool LO = false>
+// TAB: the input quantizer is the threshold table of slfp_enc.hpp (7 VALU instructions per element) instead of
+// the long form (22): the kernel was VALU-issue-bound on it (profiles/r01h).
+template <int FMT, int S, int CBT, int IWT, int V = 4, bool LO = false, bool TAB = false>
 __global__ __launch_bounds__(kDwThreads) void k_dw3x3(const float* __restrict__ x, const float* __restrict__ wq,
                                                       const float* __restrict__ bias, float* __restrict__ y,
                                                       const DwParams p) {
     using Vec = DwVec<V>;
     constexpr int VSH = V == 4 ? 0 : 1;   // log2(4 / V): lanes per pixel double with 2-float lanes
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t* sT = reinterpret_cast<uint32_t*>(smem);      // 16 dwords
-    float* tile = reinterpret_cast<float*>(smem + 64);     // [IH][IW][CB]
-    lut_fill<FMT>(sT);
+    uint32_t* sT = reinterpret_cast<uint32_t*>(smem);      // 16 dwords (long form) or the 2 KiB threshold table
+    constexpr int kTabBytes = TAB ? ((kEncEntries * 8 + 15) & ~15) : 64;
+    float* tile = reinterpret_cast<float*>(smem + kTabBytes);     // [IH][IW][CB]
+    if constexpr (TAB) enc_fill<kDwThreads>(reinterpret_cast<uint2*>(smem), p.enc);
+    else lut_fill<FMT>(sT);
     const int CB = CBT > 0 ? CBT : p.CB;
     const int IW = IWT > 0 ? IWT : p.IW;
     const int IWh = (IW + 1) / 2;
@@ -146,8 +151,19 @@ __global__ __launch_bounds__(kDwThreads) void k_dw3x3(const float* __restrict__ 
                 if (dst[u] < 0) continue;
                 Vec q;
                 // Q(0/Ka) == 0, so padded / out-of-range zeros go through the same path.
+                if constexpr (TAB) {
 #pragma unroll
-                for (int e = 0; e < V; ++e) q.v[e] = quantize_scaled<FMT>(v[u].v[e], p.sd, sT);
+                    for (int e = 0; e < V; ++e) q.v[e] = enc_f32(v[u].v[e], p.enc.r1, p.enc.lo, p.enc.hi, smem);
+                    bool un = __builtin_isunordered(v[u].v[0], v[u].v[1]);
+                    if constexpr (V == 4) un |= __builtin_isunordered(v[u].v[2], v[u].v[3]);
+                    if (__builtin_expect(un, 0)) {   // NaN in -> NaN out (never taken on real activations)
+#pragma unroll
+                        for (int e = 0; e < V; ++e) q.v[e] = v[u].v[e] != v[u].v[e] ? __uint_as_float(kBitsQNaN) : q.v[e];
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < V; ++e) q.v[e] = quantize_scaled<FMT>(v[u].v[e], p.sd, sT);
+                }
                 *reinterpret_cast<Vec*>(tile + dst[u]) = q;
             }
         }
@@ -212,6 +228,7 @@ __global__ __launch_bounds__(kDwThreads) void k_dw3x3(const float* __restrict__ 
 
 int launch_dw3x3(const slfp_conv2d_desc& d, const ConvPlan& plan, const float* x, const float* wq9c,
                  const float* bias, const PostOp& post, float* y, hipStream_t stream) {
+    if (dw3x3_tile_applicable(d, plan, bias, post)) return launch_dw3x3_tile(d, plan, x, wq9c, post, y, stream);
     DwParams p;
     p.post = post;
     p.N = (int)d.n; p.H = (int)d.h; p.W = (int)d.w; p.C = (int)d.c_in;
@@ -251,13 +268,17 @@ int launch_dw3x3(const slfp_conv2d_desc& d, const ConvPlan& plan, const float* x
     const int64_t nblocks = (int64_t)p.N * p.tiles_h * p.tiles_w * p.cgroups;
     if (nblocks > 0x7FFFFFFF) return fail(SLFP_ERR_UNSUPPORTED, "dw3x3: grid too large");
     p.nblocks = (uint32_t)nblocks;
-    const size_t lds = 64 + (size_t)p.IH * p.IW * p.CB * sizeof(float);
+    const EncArgs* tab = act_table(d.ka, plan.fmt_act, kEncF32);
+    if (tab) p.enc = *tab;
+    const size_t lds = (tab ? ((kEncEntries * 8 + 15) & ~15) : 64) + (size_t)p.IH * p.IW * p.CB * sizeof(float);
     if (lds > 64 * 1024) return fail(SLFP_ERR_UNSUPPORTED, "dw3x3: tile needs %zu B of LDS", lds);
     const bool a8 = plan.fmt_act == kFmtAct8;
 #define SLFP_DW_LAUNCH(FMT, SS, CBT, IWT, VV) \
-    hipLaunchKernelGGL((k_dw3x3<FMT, SS, CBT, IWT, VV>), dim3(p.nblocks), dim3(kDwThreads), lds, stream, x, wq9c, bias, y, p)
+    do { if (tab) hipLaunchKernelGGL((k_dw3x3<FMT, SS, CBT, IWT, VV, false, true>), dim3(p.nblocks), dim3(kDwThreads), lds, stream, x, wq9c, bias, y, p); \
+         else hipLaunchKernelGGL((k_dw3x3<FMT, SS, CBT, IWT, VV>), dim3(p.nblocks), dim3(kDwThreads), lds, stream, x, wq9c, bias, y, p); } while (0)
 #define SLFP_DW_LAUNCH_LO(FMT, SS, VV) \
-    hipLaunchKernelGGL((k_dw3x3<FMT, SS, 0, 0, VV, true>), dim3(p.nblocks), dim3(kDwThreads), lds, stream, x, wq9c, bias, y, p)
+    do { if (tab) hipLaunchKernelGGL((k_dw3x3<FMT, SS, 0, 0, VV, true, true>), dim3(p.nblocks), dim3(kDwThreads), lds, stream, x, wq9c, bias, y, p); \
+         else hipLaunchKernelGGL((k_dw3x3<FMT, SS, 0, 0, VV, true>), dim3(p.nblocks), dim3(kDwThreads), lds, stream, x, wq9c, bias, y, p); } while (0)
 #define SLFP_DW_BY_FMT(SS, CBT, IWT, VV) \
     do { if (a8) SLFP_DW_LAUNCH(kFmtAct8, SS, CBT, IWT, VV); else SLFP_DW_LAUNCH(kFmtSfp7, SS, CBT, IWT, VV); } while (0)
     if (p.post.layerout && p.post.scale) {   // fused layer-output quantizer: the generic-geometry instantiations only

@@ -46,6 +46,7 @@
 // scaling commutes with rounding), which keeps the reference's (out * Ka) * Kw roundings.
 #include <cstdlib>
 #include "slfp_device.hpp"
+#include "slfp_enc.hpp"
 #include "slfp_host.hpp"
 
 namespace slfp {
@@ -70,7 +71,22 @@ struct PwParams {
     float s1x;
     uint32_t m_blocks, n_blocks, nblocks;
     PostOp post;
+    EncArgs enc;          // threshold table of fp16(16 * QA(x / Ka)) (TAB kernels; slfp_enc.hpp)
 };
+
+constexpr int kPwTab = (kEncEntries * 8 + 15) & ~15;   // LDS bytes of the threshold table
+
+// two float4 (k = kq*4.., 16 + kq*4..) -> one MFMA B fragment through the threshold table; NaNs not patched
+__device__ __forceinline__ half8 enc_frag(const float4 a, const float4 b, const EncArgs& e, const unsigned char* tb) {
+    const uint2 pa = enc4_f16_raw(a, e.r1, e.lo, e.hi, tb), pb = enc4_f16_raw(b, e.r1, e.lo, e.hi, tb);
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    return __builtin_bit_cast(half8, u32x4{pa.x, pa.y, pb.x, pb.y});
+}
+__device__ __forceinline__ half8 enc_frag_nan(const float4 a, const float4 b, const EncArgs& e, const unsigned char* tb) {
+    const uint2 pa = enc4_f16(a, e.r1, e.lo, e.hi, tb), pb = enc4_f16(b, e.r1, e.lo, e.hi, tb);
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    return __builtin_bit_cast(half8, u32x4{pa.x, pa.y, pb.x, pb.y});
+}
 
 // element offset of input pixel row m (strided 1x1 reads pixel (oh*S, ow*S))
 __device__ __forceinline__ size_t x_row_offset(const PwParams& p, int64_t m) {
@@ -124,14 +140,19 @@ constexpr int kStreamThreads = 512;
 // KFULL: K is a multiple of 32.  A8: K and N are even but not both multiples of 4 (ShuffleNetV2's
 // 58-channel branches): pixel rows are only 8-byte aligned, so every 16-byte access becomes two
 // 8-byte ones and the per-channel vectors are read with bounds.
-template <int FMT, int PASSES, int KS, bool KFULL, bool A8 = false>
+// TAB (single-pass modes only): the quantizer is the threshold table of slfp_enc.hpp, which yields the packed fp16
+// operand directly (6 VALU instructions per element instead of 22 + convert + pack).
+template <int FMT, int PASSES, int KS, bool KFULL, bool A8 = false, bool TAB = false>
 __global__ __launch_bounds__(kStreamThreads) void k_pw_stream(const PwParams p) {
+    static_assert(!TAB || PASSES == 1, "the table form produces the single fp16 operand");
+    constexpr int TABB = TAB ? kPwTab : 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* sT = reinterpret_cast<uint32_t*>(smem);
-    _Float16* wl_hi = reinterpret_cast<_Float16*>(smem + 64);
+    _Float16* wl_hi = reinterpret_cast<_Float16*>(smem + TABB);
     const int wfrags = p.n_tiles * p.KS;  // 1 KiB each
     _Float16* wl_lo = wl_hi + (size_t)wfrags * 512;
-    lut_fill<FMT>(sT);
+    if constexpr (TAB) enc_fill<kStreamThreads>(reinterpret_cast<uint2*>(smem), p.enc);
+    else lut_fill<FMT>(sT);
     // W blob -> LDS (same fragment order), 16 bytes per thread per step
     for (int i = threadIdx.x; i < wfrags * 64; i += kStreamThreads) {
         reinterpret_cast<half8*>(wl_hi)[i] = reinterpret_cast<const half8*>(p.whi)[i];
@@ -140,7 +161,7 @@ __global__ __launch_bounds__(kStreamThreads) void k_pw_stream(const PwParams p) 
     // per-channel epilogue vectors -> LDS once per workgroup: [256 * bias/s1/s2 | post scale | post shift],
     // padded to the blob's channel count.  Read from global inside the sweep, the loads (and the 12 bias
     // divisions) sit on the critical path of every 16-byte store: +12-38 % on these layers (bench.py --post).
-    float* ep = reinterpret_cast<float*>(smem + 64 + (size_t)(PASSES == 3 ? 2 : 1) * wfrags * 1024);
+    float* ep = reinterpret_cast<float*>(smem + TABB + (size_t)(PASSES == 3 ? 2 : 1) * wfrags * 1024);
     const int n_pad = p.n_tiles * 16;
     const bool has_vec = p.bias != nullptr || p.post.scale != nullptr;   // wave-uniform
     if (has_vec) {
@@ -150,8 +171,8 @@ __global__ __launch_bounds__(kStreamThreads) void k_pw_stream(const PwParams p) 
             ep[n_pad + i] = (p.post.scale && in) ? p.post.scale[i] : 1.f;
             ep[2 * n_pad + i] = (p.post.scale && in) ? p.post.shift[i] : 0.f;
         }
-        __syncthreads();
     }
+    __syncthreads();
 
     const int lane = threadIdx.x & 63;
     const int col = lane & 15, kq = lane >> 4;
@@ -193,13 +214,26 @@ __global__ __launch_bounds__(kStreamThreads) void k_pw_stream(const PwParams p) 
                     }
                 }
             }
+            if constexpr (TAB) {
+                bool any_nan = false;
 #pragma unroll
-            for (int c = 0; c < CH; ++c) {
-                half4 h0, h1, l0, l1;
-                encode4<FMT, PASSES>(raw[c][0], p.sd, sT, h0, l0);
-                encode4<FMT, PASSES>(raw[c][1], p.sd, sT, h1, l1);
-                xh[c0 + c] = join(h0, h1);
-                if constexpr (PASSES == 3) xl[c0 + c] = join(l0, l1);
+                for (int c = 0; c < CH; ++c) {
+                    any_nan |= enc_has_nan4(raw[c][0]) | enc_has_nan4(raw[c][1]);
+                    xh[c0 + c] = enc_frag(raw[c][0], raw[c][1], p.enc, smem);
+                }
+                if (__builtin_expect(any_nan, 0)) {   // NaN in -> NaN out; never taken on real activations
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) xh[c0 + c] = enc_frag_nan(raw[c][0], raw[c][1], p.enc, smem);
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    half4 h0, h1, l0, l1;
+                    encode4<FMT, PASSES>(raw[c][0], p.sd, sT, h0, l0);
+                    encode4<FMT, PASSES>(raw[c][1], p.sd, sT, h1, l1);
+                    xh[c0 + c] = join(h0, h1);
+                    if constexpr (PASSES == 3) xl[c0 + c] = join(l0, l1);
+                }
             }
             // keep the chunks sequential: without this hipcc hoists every load of every chunk
             // to the top and runs out of registers at K = 256
@@ -260,8 +294,10 @@ __device__ __forceinline__ uint32_t lds_x_off(int row, int chunk16) {
 // output tiles are clamped and never stored) and the loop body has no branches: with a
 // per-load `if` hipcc cannot count the loads in flight and falls back to s_waitcnt vmcnt(0)
 // in the middle of the MFMA block, draining the HBM loads it has just issued (r01c ISA).
-template <int FMT, int PASSES, int WM, int WN, int MT, int NT, bool KFULL>
+template <int FMT, int PASSES, int WM, int WN, int MT, int NT, bool KFULL, bool TAB = false>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 4) void k_pw_tiled(const PwParams p) {
+    static_assert(!TAB || PASSES == 1, "the table form produces the single fp16 operand");
+    constexpr int TABB = TAB ? kPwTab : 64;
     constexpr int T = 64 * WM * WN;
     constexpr int BM = WM * MT * 16;
     constexpr int BN = WN * NT * 16;
@@ -271,8 +307,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 4) void k_pw_til
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* sT = reinterpret_cast<uint32_t*>(smem);
-    unsigned char* xs = smem + 64;  // [2 buffers][hi, lo][BM rows][128 B]
-    lut_fill<FMT>(sT);
+    unsigned char* xs = smem + TABB;  // [2 buffers][hi, lo][BM rows][128 B]
+    if constexpr (TAB) enc_fill<T>(reinterpret_cast<uint2*>(smem), p.enc);
+    else lut_fill<FMT>(sT);
 
     const uint32_t b = xcd_remap(blockIdx.x, p.nblocks);
     const uint32_t nb = b % p.n_blocks, mb = b / p.n_blocks;
@@ -314,11 +351,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 4) void k_pw_til
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int row = (threadIdx.x >> 4) + i * (T / 16);
-            half4 h, l;
-            encode4<FMT, PASSES>(st[i], p.sd, sT, h, l);
             const uint32_t off = lds_x_off(row, st_chunk) + st_sub;
-            *reinterpret_cast<half4*>(hi + off) = h;
-            if constexpr (PASSES == 3) *reinterpret_cast<half4*>(lo + off) = l;
+            if constexpr (TAB) {
+                *reinterpret_cast<uint2*>(hi + off) = enc4_f16(st[i], p.enc.r1, p.enc.lo, p.enc.hi, smem);
+            } else {
+                half4 h, l;
+                encode4<FMT, PASSES>(st[i], p.sd, sT, h, l);
+                *reinterpret_cast<half4*>(hi + off) = h;
+                if constexpr (PASSES == 3) *reinterpret_cast<half4*>(lo + off) = l;
+            }
         }
     };
 
@@ -446,6 +487,16 @@ static int launch_tiled_k(PwParams& p, hipStream_t stream) {
     const int64_t nblocks = (int64_t)p.m_blocks * p.n_blocks;
     if (nblocks > 0x7FFFFFFF) return fail(SLFP_ERR_UNSUPPORTED, "pointwise: grid too large");
     p.nblocks = (uint32_t)nblocks;
+    if constexpr (PASSES == 1) {
+        if (p.enc.valid) {
+            const size_t lds = kPwTab + (size_t)2 * BM * 128;
+            auto fn = k_pw_tiled<FMT, 1, WM, WN, MT, NT, KFULL, true>;
+            int rc = set_lds_limit(reinterpret_cast<const void*>(fn), lds);
+            if (rc != SLFP_OK) return rc;
+            hipLaunchKernelGGL(fn, dim3(p.nblocks), dim3(T), lds, stream, p);
+            return check_launch("slfp pointwise (tiled) kernel");
+        }
+    }
     const size_t lds = 64 + (size_t)2 * (PASSES == 3 ? 2 : 1) * BM * 128;
     auto fn = k_pw_tiled<FMT, PASSES, WM, WN, MT, NT, KFULL>;
     int rc = set_lds_limit(reinterpret_cast<const void*>(fn), lds);
@@ -462,9 +513,15 @@ static int launch_tiled(PwParams& p, hipStream_t stream) {
 
 template <int FMT, int PASSES, int KS>
 static int launch_stream_ks(PwParams& p, hipStream_t stream) {
-    const size_t lds = 64 + (size_t)(PASSES == 3 ? 2 : 1) * p.n_tiles * p.KS * 1024 + (size_t)3 * p.n_tiles * 16 * sizeof(float);
+    bool tab = false;
+    if constexpr (PASSES == 1) tab = p.enc.valid != 0;
+    const size_t lds = (tab ? kPwTab : 64) + (size_t)(PASSES == 3 ? 2 : 1) * p.n_tiles * p.KS * 1024 + (size_t)3 * p.n_tiles * 16 * sizeof(float);
     auto fn = (p.K % 4 || p.N % 4) ? k_pw_stream<FMT, PASSES, KS, false, true>
               : (p.K % 32 == 0)    ? k_pw_stream<FMT, PASSES, KS, true> : k_pw_stream<FMT, PASSES, KS, false>;
+    if constexpr (PASSES == 1) {
+        if (tab) fn = (p.K % 4 || p.N % 4) ? k_pw_stream<FMT, 1, KS, false, true, true>
+                      : (p.K % 32 == 0)    ? k_pw_stream<FMT, 1, KS, true, false, true> : k_pw_stream<FMT, 1, KS, false, false, true>;
+    }
     int rc = set_lds_limit(reinterpret_cast<const void*>(fn), lds);
     if (rc != SLFP_OK) return rc;
     // persistent grid: as many workgroups per CU as LDS allows (<= 4), 256 CUs
@@ -527,6 +584,10 @@ int launch_pointwise(const slfp_conv2d_desc& d, const ConvPlan& plan, const floa
     p.H = (int)d.h; p.W = (int)d.w; p.Ho = (int)plan.h_out; p.Wo = (int)plan.w_out; p.S = d.stride_h;
     p.M = d.n * plan.h_out * plan.w_out;
     p.sd = make_scale_div(d.ka, 4);  // x / (Ka/16) == 16 * (x / Ka)
+    p.enc.valid = 0;
+    if (plan.passes == 1 && !getenv("SLFP_PW_NOTAB")) {   // SLFP_PW_NOTAB: per-call A/B switch (profiles/variants.py)
+        if (const EncArgs* t = act_table(d.ka, plan.fmt_act, kEncF16P)) p.enc = *t;
+    }
     p.s1 = plan.s1; p.s2 = plan.s2; p.s1x = plan.s1 * (1.0f / 256.0f);
     if (plan.fmt_act == kFmtSfp7) return launch_pw<kFmtSfp7, 1>(p, plan, stream);  // exact in fp16
     if (plan.passes == 3) return launch_pw<kFmtAct8, 3>(p, plan, stream);

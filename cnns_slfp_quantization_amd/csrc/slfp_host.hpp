@@ -5,8 +5,10 @@
 #include <stddef.h>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 #include "../../include/slfp.h"
 #include "slfp_device.hpp"
+#include "slfp_enc.hpp"
 
 namespace slfp {
 
@@ -30,6 +32,21 @@ inline ScaleDiv make_scale_div(float d, int esh = 0) {
     s.d = std::ldexp(d, -esh);  // dividing by d/2^esh == multiplying the quotient by 2^esh, exactly
     s.r = (float)(1.0 / (double)s.d);
     return s;
+}
+
+// SLFP_LONG_ENCODE=1 in the environment keeps every kernel on the long-form quantizer (slfp_device.hpp) instead of the
+// threshold table (slfp_enc.hpp): the A/B switch of profiles/ab_compare.sh and of the parity tests.
+inline bool long_encode_forced() {
+    static const bool v = std::getenv("SLFP_LONG_ENCODE") != nullptr;
+    return v;
+}
+// SLFP_DW_OLD=1: keep every depthwise layer on conv_dw.hip (A/B switch, profiles/variants.py); read per call.
+inline bool dw_old_forced() { return std::getenv("SLFP_DW_OLD") != nullptr; }
+// The table for the activation side of a layer, or nullptr when the long form has to be used.
+inline const EncArgs* act_table(float ka, int fmt_act, int rep) {
+    if (long_encode_forced()) return nullptr;
+    const EncArgs* t = enc_table(ka, fmt_act, rep);
+    return t->valid ? t : nullptr;
 }
 
 // Kernel families (slfp_conv2d_kernel_name reports them).
@@ -61,6 +78,10 @@ int make_plan(const slfp_conv2d_desc* d, ConvPlan* plan);
 int launch_quantize(const float* x, float* y, size_t n, float scale, int fmt, hipStream_t stream);
 int launch_dw3x3(const slfp_conv2d_desc& d, const ConvPlan& p, const float* x, const float* wq9c,
                  const float* bias, const PostOp& post, float* y, hipStream_t stream);
+// the straight-line depthwise tile kernel (conv_dw2.hip): C a multiple of 32, threshold table available
+bool dw3x3_tile_applicable(const slfp_conv2d_desc& d, const ConvPlan& p, const float* bias, const PostOp& post);
+int launch_dw3x3_tile(const slfp_conv2d_desc& d, const ConvPlan& p, const float* x, const float* wq9c,
+                      const PostOp& post, float* y, hipStream_t stream);
 int launch_pointwise(const slfp_conv2d_desc& d, const ConvPlan& p, const float* x, const void* wfrag,
                      const float* bias, const PostOp& post, float* y, hipStream_t stream);
 int launch_direct(const slfp_conv2d_desc& d, const ConvPlan& p, const float* x, const float* wq_hwio,

@@ -43,10 +43,6 @@ class ConvSpec:
 
     @property
     def macs(self):
-        return self.out_elems * (self.c_in // self.groups) * self.k[0] * self.k[1]
-
-    @property
-    def macs(self):
         """Multiply-accumulates per image."""
         return self.h_out * self.w_out * self.c_out * (self.c_in // self.groups) * self.k[0] * self.k[1]
 

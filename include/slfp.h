@@ -164,6 +164,16 @@ int slfp_linear_fwd_prepared(const float* x, const void* wprep, const float* bia
  * out2[1] = inputs (all 2^32) for which any quantizer result would differ.  Both must be 0. */
 int slfp_debug_div_mismatches(float scale_div, unsigned long long* out2, void* stream);
 
+/* The conv kernels evaluate QA(x / Ka) through a per-Ka threshold table (csrc/slfp_enc.hpp: one approximate
+ * multiply picks a bin, one exact compare in x-space picks the side) instead of the long form above.  The table is
+ * built and proven on the host per (Ka, format); this sweeps ALL 2^32 float32 inputs on the device and writes
+ * out2[0] = inputs whose float32 result differs from the long form, out2[1] = inputs whose fp16 MFMA-operand
+ * result differs (+0 / -0 counted as equal).  Both must be 0.  fmt: SLFP_FMT_ACT8 or SLFP_FMT_SFP7.
+ * Returns SLFP_ERR_UNSUPPORTED if no table can be proven for this scale (the kernels then use the long form). */
+int slfp_debug_enc_mismatches(float scale_div, int fmt, unsigned long long* out2, void* stream);
+/* 1 if the threshold table exists for this scale / format (host-only query, no device work). */
+int slfp_enc_table_ok(float scale_div, int fmt);
+
 /* ---- layout helpers (the reference is NCHW; the kernels are NHWC) -------------------- */
 int slfp_nchw_to_nhwc_f32(const float* x, float* y, int64_t n, int64_t c, int64_t h, int64_t w, void* stream);
 int slfp_nhwc_to_nchw_f32(const float* x, float* y, int64_t n, int64_t c, int64_t h, int64_t w, void* stream);

@@ -262,6 +262,26 @@ def test_constant_division_is_ieee_exact_for_all_2_32_inputs(lib, dev):
             assert bad[0] == 0 and bad[1] == 0, (sc, bad)
 
 
+def test_threshold_table_quantizer_equals_long_form_for_all_2_32_inputs(lib, dev):
+    """The conv kernels evaluate QA(x/Ka) through a per-Ka threshold table (csrc/slfp_enc.hpp).  Sweep every
+    float32 bit pattern on the device for a spread of scales (net literals, round numbers, all-ones
+    significands, both formats): the table form must equal the long form (itself golden-pinned) bit for bit,
+    as float32 and as the fp16 MFMA operand."""
+    L = lib.load()
+    from cnns_slfp_quantization_amd import layer_specs
+    kas = sorted({float(np.float32(r["Ka"])) for net in layer_specs.nets().values() for r in net["layers"]})
+    scales = kas[:: max(1, len(kas) // 12)] + [1.0, 3.0, 0.1, 1.0 / 3.0, 1e-3, 977.0, float(np.float32(1.9999999)),
+                                                 float(np.uint32(0x3DFFFFFF).view(np.float32)),
+                                                 float(np.nextafter(np.float32(1.0), np.float32(2.0)))]
+    out = torch.zeros(2, dtype=torch.int64, device=dev)
+    for sc in scales:
+        for fmt in (lib.FMT_ACT8, lib.FMT_SFP7):
+            assert L.slfp_enc_table_ok(float(np.float32(sc)), fmt) == 1, (sc, fmt)
+            lib.check(L.slfp_debug_enc_mismatches(float(np.float32(sc)), fmt, out.data_ptr(), _stream()))
+            bad = out.cpu().numpy()
+            assert bad[0] == 0 and bad[1] == 0, (sc, fmt, bad)
+
+
 # ------------------------------------------------------------------ conv: MobileNetV1 layer shapes vs the oracle
 def _raw_conv(lib, dev, x_nhwc, w_oihw, bias, stride, pad, groups, Ka, Kw, qbits, passes=0):
     """Straight through the C ABI (no torch module): NHWC in, NHWC out."""
