@@ -70,6 +70,7 @@ struct PwParams {
     float s1, s2;         // out = ((acc/256 + bias/s1/s2) * s1) * s2 ; s1x = s1/256
     float s1x;
     uint32_t m_blocks, n_blocks, nblocks;
+    int rb;               // k_pw_tiled: pixel rows a workgroup really owns (<= BM; the rest of its tile is padding)
     PostOp post;
     EncArgs enc;          // threshold table of fp16(16 * QA(x / Ka)) (TAB kernels; slfp_enc.hpp)
 };
@@ -142,9 +143,13 @@ constexpr int kStreamThreads = 512;
 // 8-byte ones and the per-channel vectors are read with bounds.
 // TAB (single-pass modes only): the quantizer is the threshold table of slfp_enc.hpp, which yields the packed fp16
 // operand directly (6 VALU instructions per element instead of 22 + convert + pack).
-template <int FMT, int PASSES, int KS, bool KFULL, bool A8 = false, bool TAB = false>
+// STG (with TAB): the outputs of two channel tiles at a time go through a 2 KiB per-wave LDS buffer and leave as 128-byte
+// pieces (8 pixels x 32 channels per store instruction) instead of the accumulator layout's 64-byte pieces (16 pixels x
+// 16 channels): HBM writes of 64-byte pieces run at about half the rate (profiles/micro/bw_patterns.hip).
+template <int FMT, int PASSES, int KS, bool KFULL, bool A8 = false, bool TAB = false, bool STG = false>
 __global__ __launch_bounds__(kStreamThreads) void k_pw_stream(const PwParams p) {
     static_assert(!TAB || PASSES == 1, "the table form produces the single fp16 operand");
+    static_assert(!STG || (TAB && !A8), "staged stores: table kernels with 16-byte channel alignment");
     constexpr int TABB = TAB ? kPwTab : 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* sT = reinterpret_cast<uint32_t*>(smem);
@@ -163,6 +168,7 @@ __global__ __launch_bounds__(kStreamThreads) void k_pw_stream(const PwParams p) 
     // divisions) sit on the critical path of every 16-byte store: +12-38 % on these layers (bench.py --post).
     float* ep = reinterpret_cast<float*>(smem + TABB + (size_t)(PASSES == 3 ? 2 : 1) * wfrags * 1024);
     const int n_pad = p.n_tiles * 16;
+    unsigned char* stg = reinterpret_cast<unsigned char*>(ep + 3 * n_pad) + (threadIdx.x >> 6) * 2048;   // STG: this wave's 2 KiB
     const bool has_vec = p.bias != nullptr || p.post.scale != nullptr;   // wave-uniform
     if (has_vec) {
         for (int i = threadIdx.x; i < n_pad; i += kStreamThreads) {
@@ -240,8 +246,7 @@ __global__ __launch_bounds__(kStreamThreads) void k_pw_stream(const PwParams p) 
             if constexpr (KS > CH) asm volatile("" ::: "memory");
         }
         // ---- sweep the output-channel tiles
-        float* yr = p.y + (size_t)m * p.N + kq * 4;
-        for (int j = 0; j < p.n_tiles; ++j) {
+        auto tile_out = [&](int j) {
             floatx4 acc = floatx4{0.f, 0.f, 0.f, 0.f};
             const _Float16* wj = wl_hi + ((size_t)j * p.KS) * 512 + lane * 8;
 #pragma unroll
@@ -270,11 +275,39 @@ __global__ __launch_bounds__(kStreamThreads) void k_pw_stream(const PwParams p) 
                 r = epilogue(acc, make_float4(0.f, 0.f, 0.f, 0.f), p.s1x, p.s2);
             }
             if (p.post.relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
-            if constexpr (A8) {
-                if (live && n < p.N) *reinterpret_cast<float2*>(yr + j * 16) = make_float2(r.x, r.y);
-                if (live && n + 2 < p.N) *reinterpret_cast<float2*>(yr + j * 16 + 2) = make_float2(r.z, r.w);
-            } else {
-                if (live && n < p.N) *reinterpret_cast<float4*>(yr + j * 16) = r;
+            return r;
+        };
+        if constexpr (STG) {
+            // per-unit descriptor: rows beyond M and channels beyond N get an out-of-range offset (store dropped)
+            const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+                p.y + (size_t)g * 16 * p.N, 0, (uint32_t)(((uint64_t)(p.M - g * 16) * p.N * 4) > 0xFFFFFFFFull ? 0xFFFFFFFFull : ((uint64_t)(p.M - g * 16) * p.N * 4)), 0x00020000);
+            const int spx = lane >> 3, sch = lane & 7;
+            for (int j0 = 0; j0 < p.n_tiles; j0 += 2) {
+                const float4 ra = tile_out(j0), rb = tile_out(j0 + 1);
+                *reinterpret_cast<float4*>(stg + col * 128 + kq * 16) = ra;
+                *reinterpret_cast<float4*>(stg + col * 128 + 64 + kq * 16) = rb;
+                // LDS operations of one wave execute in order: the reads see the writes, the next pair's writes follow the reads
+                const bool ch_ok = (j0 * 16 + sch * 4) < p.N;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(stg + lane * 16 + h * 1024);
+                    uint32_t so = ch_ok ? (uint32_t)((spx + 8 * h) * p.N + j0 * 16 + sch * 4) * 4u : 0xFFFFFFF0u;
+                    asm volatile("" : "+v"(so));
+                    __builtin_amdgcn_raw_buffer_store_b128(v, ry, so, 0, 0);
+                }
+            }
+        } else {
+            float* yr = p.y + (size_t)m * p.N + kq * 4;
+            for (int j = 0; j < p.n_tiles; ++j) {
+                const float4 r = tile_out(j);
+                const int n = j * 16 + kq * 4;
+                if constexpr (A8) {
+                    if (live && n < p.N) *reinterpret_cast<float2*>(yr + j * 16) = make_float2(r.x, r.y);
+                    if (live && n + 2 < p.N) *reinterpret_cast<float2*>(yr + j * 16 + 2) = make_float2(r.z, r.w);
+                } else {
+                    if (live && n < p.N) *reinterpret_cast<float4*>(yr + j * 16) = r;
+                }
             }
         }
     }
@@ -313,7 +346,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 4) void k_pw_til
 
     const uint32_t b = xcd_remap(blockIdx.x, p.nblocks);
     const uint32_t nb = b % p.n_blocks, mb = b / p.n_blocks;
-    const int64_t m0 = (int64_t)mb * BM;
+    const int64_t m0 = (int64_t)mb * p.rb;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int col = lane & 15, kq = lane >> 4;
@@ -326,8 +359,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 4) void k_pw_til
     const float* src[NLD];
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-        int64_t m = m0 + (threadIdx.x >> 4) + i * (T / 16);
-        m = m < p.M ? m : p.M - 1;  // clamp: rows past the end are computed and dropped
+        const int row = (threadIdx.x >> 4) + i * (T / 16);
+        int64_t m = m0 + (row < p.rb ? row : p.rb - 1);  // padding rows of the tile re-read its last row (L1 hits) ...
+        m = m < p.M ? m : p.M - 1;                       // ... and rows past the end the last pixel: computed and dropped
         src[i] = p.x + x_row_offset(p, m) + kc * 4;
     }
 
@@ -453,8 +487,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 4) void k_pw_til
         const float4 bq = bias_q256(p, n);
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-            const int64_t m = m0 + (wm * MT + i) * 16 + col;
-            if (m >= p.M) continue;
+            const int row = (wm * MT + i) * 16 + col;
+            const int64_t m = m0 + row;
+            if (m >= p.M || row >= p.rb) continue;
             float4 r = epilogue(acc[i][j], bq, p.s1x, p.s2);
             if (p.post.scale) {
                 const float4 sc = *reinterpret_cast<const float4*>(lsc + (n - n_lo));
@@ -482,8 +517,24 @@ static int set_lds_limit(const void* fn, size_t lds) {
 template <int FMT, int PASSES, int WM, int WN, int MT, int NT, bool KFULL>
 static int launch_tiled_k(PwParams& p, hipStream_t stream) {
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16, T = 64 * WM * WN;
-    p.m_blocks = (uint32_t)ceil_div(p.M, BM);
     p.n_blocks = (uint32_t)ceil_div((int64_t)p.N, BN);
+    // Rows per workgroup.  All workgroups cost the same, so ceil(workgroups / resident slots) rounds of rb rows decide
+    // the time: MobileNetV1's 14x14 layers are 784 full tiles on 512 slots = 2 rounds of 64 rows, but 1024 tiles of 49
+    // rows (one quarter image, padded to 64 for the MFMA) = 2 rounds of 49 rows: 23 % less.  Pick the rb in
+    // (BM/2, BM] with the smallest rounds * rb; the padding rows cost MFMA work only (the kernels are HBM-bound).
+    {
+        const int64_t slots = 256 * ((WM * WN) <= 4 ? 4 : 2);   // resident workgroups (register-limited: 16 waves per CU)
+        int best = BM;
+        int64_t best_cost = ceil_div(ceil_div(p.M, BM) * p.n_blocks, slots) * BM;
+        if (!getenv("SLFP_PW_FULLTILES")) {
+            for (int rb = BM - 1; rb > BM / 2; --rb) {
+                const int64_t cost = ceil_div(ceil_div(p.M, rb) * p.n_blocks, slots) * rb;
+                if (cost < best_cost) { best_cost = cost; best = rb; }
+            }
+        }
+        p.rb = best;
+    }
+    p.m_blocks = (uint32_t)ceil_div(p.M, p.rb);
     const int64_t nblocks = (int64_t)p.m_blocks * p.n_blocks;
     if (nblocks > 0x7FFFFFFF) return fail(SLFP_ERR_UNSUPPORTED, "pointwise: grid too large");
     p.nblocks = (uint32_t)nblocks;
@@ -515,12 +566,17 @@ template <int FMT, int PASSES, int KS>
 static int launch_stream_ks(PwParams& p, hipStream_t stream) {
     bool tab = false;
     if constexpr (PASSES == 1) tab = p.enc.valid != 0;
-    const size_t lds = (tab ? kPwTab : 64) + (size_t)(PASSES == 3 ? 2 : 1) * p.n_tiles * p.KS * 1024 + (size_t)3 * p.n_tiles * 16 * sizeof(float);
+    // staged 128-byte stores pay where stores dominate and follow each other closely (K <= 64: pw1 -14 %, pw2 -13 %);
+    // neutral at K = 128, a loss at K = 256 (same-box A/B, profiles/variants.py)
+    const bool stg = tab && KS <= 2 && !(p.K % 4 || p.N % 4) && !getenv("SLFP_PW_NOSTG");
+    const size_t lds = (tab ? kPwTab : 64) + (size_t)(PASSES == 3 ? 2 : 1) * p.n_tiles * p.KS * 1024 + (size_t)3 * p.n_tiles * 16 * sizeof(float) +
+                       (stg ? (size_t)(kStreamThreads / 64) * 2048 : 0);
     auto fn = (p.K % 4 || p.N % 4) ? k_pw_stream<FMT, PASSES, KS, false, true>
               : (p.K % 32 == 0)    ? k_pw_stream<FMT, PASSES, KS, true> : k_pw_stream<FMT, PASSES, KS, false>;
     if constexpr (PASSES == 1) {
         if (tab) fn = (p.K % 4 || p.N % 4) ? k_pw_stream<FMT, 1, KS, false, true, true>
                       : (p.K % 32 == 0)    ? k_pw_stream<FMT, 1, KS, true, false, true> : k_pw_stream<FMT, 1, KS, false, false, true>;
+        if (stg) fn = (p.K % 32 == 0) ? k_pw_stream<FMT, 1, KS, true, false, true, true> : k_pw_stream<FMT, 1, KS, false, false, true, true>;
     }
     int rc = set_lds_limit(reinterpret_cast<const void*>(fn), lds);
     if (rc != SLFP_OK) return rc;

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--passes", type=int, default=1)
     ap.add_argument("--post", action="store_true")
+    ap.add_argument("--layers", default="", help="comma-separated indices into the family's layers (default all)")
     args = ap.parse_args()
     L = _lib.load()
     dev = torch.device("cuda", 0)
@@ -37,9 +38,11 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     layers = [bench.Layer(L, s, args.batch, dev, args.passes, gen, 8, args.post) for s in layer_specs.conv_layers(args.net)]
     layers = [l for l in layers if args.family in l.kernel]
+    if args.layers:
+        layers = [layers[int(i)] for i in args.layers.split(",")]
     for l in layers:
         l.prepare(L, stream)
-    variants = [("default", {})] + [(v, dict([v.split("=", 1)])) for v in args.var]
+    variants = [("default", {})] + [(v, dict(kv.split("=", 1) for kv in v.split(","))) for v in args.var]
     keys = {k for _, e in variants for k in e}
     times = {name: [[] for _ in layers] for name, _ in variants}
     for r in range(args.rounds + 1):
