@@ -518,22 +518,10 @@ template <int FMT, int PASSES, int WM, int WN, int MT, int NT, bool KFULL>
 static int launch_tiled_k(PwParams& p, hipStream_t stream) {
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16, T = 64 * WM * WN;
     p.n_blocks = (uint32_t)ceil_div((int64_t)p.N, BN);
-    // Rows per workgroup.  All workgroups cost the same, so ceil(workgroups / resident slots) rounds of rb rows decide
-    // the time: MobileNetV1's 14x14 layers are 784 full tiles on 512 slots = 2 rounds of 64 rows, but 1024 tiles of 49
-    // rows (one quarter image, padded to 64 for the MFMA) = 2 rounds of 49 rows: 23 % less.  Pick the rb in
-    // (BM/2, BM] with the smallest rounds * rb; the padding rows cost MFMA work only (the kernels are HBM-bound).
-    {
-        const int64_t slots = 256 * ((WM * WN) <= 4 ? 4 : 2);   // resident workgroups (register-limited: 16 waves per CU)
-        int best = BM;
-        int64_t best_cost = ceil_div(ceil_div(p.M, BM) * p.n_blocks, slots) * BM;
-        if (!getenv("SLFP_PW_FULLTILES")) {
-            for (int rb = BM - 1; rb > BM / 2; --rb) {
-                const int64_t cost = ceil_div(ceil_div(p.M, rb) * p.n_blocks, slots) * rb;
-                if (cost < best_cost) { best_cost = cost; best = rb; }
-            }
-        }
-        p.rb = best;
-    }
+    // (Workgroups that own fewer rows than their tile -- 49 = a quarter image instead of 64, for an integral number of
+    // rounds on the 512 resident slots -- were measured: no gain, 61-64 vs 60 us on 512->512.  A workgroup's time is set
+    // by streaming all of W from L2, not by its rows.)
+    p.rb = BM;
     p.m_blocks = (uint32_t)ceil_div(p.M, p.rb);
     const int64_t nblocks = (int64_t)p.m_blocks * p.n_blocks;
     if (nblocks > 0x7FFFFFFF) return fail(SLFP_ERR_UNSUPPORTED, "pointwise: grid too large");
