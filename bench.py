@@ -85,6 +85,16 @@ class Layer:
         _lib.check(L.slfp_conv2d_prepare_weights(ctypes.byref(self.desc), self.w.data_ptr(), self.blob.data_ptr(),
                                                  None, stream))
 
+    def encode_codes(self, L, stream):
+        """u8 codes of QW(w / Kw) (1 B per weight, extended code points): what travels between ranks."""
+        fmt = (_lib.FMT_W8 if self.desc.qbits == 8 else _lib.FMT_SFP7) | _lib.FMT_EXT
+        codes = torch.empty(self.w.numel(), dtype=torch.uint8, device=self.w.device)
+        _lib.check(L.slfp_encode_f32(self.w.data_ptr(), codes.data_ptr(), self.w.numel(), float(self.desc.kw_scale), fmt, stream))
+        return codes
+
+    def prepare_from_codes(self, L, stream, codes):
+        _lib.check(L.slfp_conv2d_prepare_weights_codes(ctypes.byref(self.desc), codes.data_ptr(), self.blob.data_ptr(), None, stream))
+
     def run(self, L, stream):
         if self.post is not None:
             rc = L.slfp_conv2d_fwd_post(ctypes.byref(self.desc), self.x.data_ptr(), self.blob.data_ptr(),
@@ -243,7 +253,183 @@ def cpu_baseline(specs, sample_batch, iters):
     return {"value": round(sample_batch * iters / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(),
             "kind": "port",
             "sample": f"{iters} x batch {sample_batch} through the same {len(specs)} Conv2d_Q layers, "
-                      f"oracle/torch_port.py (the reference's ATen op sequence) on PyTorch-CPU, no_grad"}
+                      f"oracle/torch_port.py (the reference's ATen op sequence minus its three .clone() passes per "
+                      f"quantizer: ~1.7x faster than the reference's own modules on the same layer, i.e. a conservative "
+                      f"baseline) on PyTorch-CPU, no_grad"}
+
+
+def pmc_field(family, net, batch, field):
+    """Launch-weighted mean of a derived field (e.g. mfma_busy_frac) of `family` in the newest committed PMC summary."""
+    try:
+        index = json.load(open(os.path.join(ROOT, "profiles", "index.json")))
+    except OSError:
+        return None
+    for ent in reversed(index):
+        if ent["net"] != net or ent["batch"] != batch:
+            continue
+        path = os.path.join(ROOT, "profiles", ent["tag"] + "_summary.json")
+        if not os.path.exists(path):
+            continue
+        tot = n = 0.0
+        for r in json.load(open(path)):
+            if r["kernel"].split("<")[0] in FAMILY_KERNELS.get(family, ()) and field in r:
+                w = r["launches"] * r.get("avg_us", 1.0)
+                tot += r[field] * w
+                n += w
+        if n:
+            return round(tot / n, 4)
+    return None
+
+
+def timed_steps(step, steps, world, dev):
+    """EXACTLY `steps` steps between barrier + synchronize on both sides; returns this rank's seconds."""
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
+def run_config(L, net, batch, qbits, passes, steps, warmup, dev, rank, world, post=False, per_layer=False, exact_too=False):
+    """One workload: every Conv2d_Q layer of `net` at `batch` images on this rank.  Returns (result dict, per-rank seconds)."""
+    specs = layer_specs.conv_layers(net)
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    layers = [Layer(L, s, batch, dev, passes, gen, qbits, post) for s in specs]
+    stream = torch.cuda.current_stream().cuda_stream
+    # Quantized weights: rank 0 encodes them ONCE to u8 codes (1 B per weight), the codes of all layers travel as one
+    # bucket (the only collective of the whole path: RCCL broadcast over xGMI, sharding.py), and every rank lays them
+    # out for its own kernels (slfp_conv2d_prepare_weights_codes: identical to preparing from the weights).
+    if world > 1:
+        codes = [l.encode_codes(L, stream) if rank == 0 else torch.empty(l.w.numel(), dtype=torch.uint8, device=dev) for l in layers]
+        torch.cuda.synchronize()
+        sharding.broadcast_blobs(codes, src=0)
+        for l, c in zip(layers, codes):
+            l.prepare_from_codes(L, stream, c)
+        del codes
+    else:
+        for l in layers:
+            l.prepare(L, stream)
+    torch.cuda.synchronize()
+
+    def step():
+        for l in layers:
+            l.run(L, stream)
+
+    for _ in range(warmup):
+        step()
+    dt_rank = timed_steps(step, steps, world, dev)
+    rank_dts = sharding.rank_times(dt_rank, device=dev)   # every rank's seconds; the job's time is the slowest rank's
+    dt = max(rank_dts)
+
+    # ---- per-kernel timing with HIP events on the launch stream (separate pass, same step order: cold caches)
+    ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in layers] for _ in range(steps)]
+    for k in range(steps):
+        for i, l in enumerate(layers):
+            ev[k][i][0].record()
+            l.run(L, stream)
+            ev[k][i][1].record()
+    torch.cuda.synchronize()
+    layer_ms = [float(np.mean([ev[k][i][0].elapsed_time(ev[k][i][1]) for k in range(steps)])) for i in range(len(layers))]
+    fam = {}
+    for l, ms in zip(layers, layer_ms):
+        f = fam.setdefault(l.kernel, {"ms": 0.0, "bytes": 0, "launches": 0, "flops": 0})
+        f["ms"] += ms
+        f["bytes"] += l.bytes
+        f["flops"] += 2 * l.spec.macs * l.batch
+        f["launches"] += 1
+    dominant = max(fam, key=lambda k: fam[k]["ms"])
+    dom = fam[dominant]
+    dom_gbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+
+    exact_value = None
+    if exact_too and passes == 0 and qbits == 8:   # the float32-equivalent mode (fp16 hi/lo split, 3 MFMA passes), same buffers
+        for l in layers:
+            l.set_passes(L, stream, _lib.MFMA_F16X3)
+        step()
+        dte = max(sharding.rank_times(timed_steps(step, steps, world, dev), device=dev))
+        exact_value = batch * world * steps / dte
+        for l in layers:
+            l.set_passes(L, stream, passes)
+
+    imgs = batch * world * steps
+    value = imgs / dt
+    bytes_img = layer_specs.algorithmic_bytes_per_image(net, batch)
+    whole_gbs = bytes_img * value / 1e9 / world  # per GPU
+    res = {
+        "value": round(value, 1), "ms_per_step": round(dt / steps * 1e3, 4),
+        "hbm_roofline_frac_whole_path": round(whole_gbs / HBM_PEAK_GBS, 4),
+        "algorithmic_bytes_per_image": int(bytes_img),
+        "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(dom_gbs, 1), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(dom_gbs / HBM_PEAK_GBS, 4),
+                     "frac_of_measured_copy_ceiling": round(dom_gbs / HBM_COPY_GBS, 4),
+                     "traffic": pmc_traffic(dominant, net, batch)[0],
+                     "traffic_profile": pmc_traffic(dominant, net, batch)[1],
+                     "mfma_busy_frac": pmc_field(dominant, net, batch, "mfma_busy_frac"),
+                     "launches_per_step": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
+                     "algorithmic_bytes_per_launch": int(dom["bytes"] / dom["launches"])},
+        "kernels": {k: {"ms_per_step": round(v["ms"], 4), "GB/s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
+                        "TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1), "launches": v["launches"]}
+                    for k, v in fam.items()},
+        "pointwise_mfma": next((l.kernel for l in layers if l.kernel.startswith("pw_")), None),
+        "n_layers": len(layers),
+    }
+    if dominant.startswith(("dense_mfma", "stem_mfma_")):
+        # compute-bound families (VGG-16 / ResNet-50 3x3, large stems): price against the matrix cores.
+        # achieved = algorithmic flops (2 * MACs of the layers) / measured time incl. the fp16 encode pre-pass
+        tf = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        res["roofline"] = {"bound": "mfma", "kernel": dominant, "achieved": round(tf, 1), "peak": MFMA_F16_PEAK_TFLOPS,
+                           "unit": "TFLOP/s", "frac": round(tf / MFMA_F16_PEAK_TFLOPS, 4), "traffic": None,
+                           "mfma_busy_frac": pmc_field(dominant, net, batch, "mfma_busy_frac"),
+                           "launches_per_step": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
+                           "algorithmic_flops_per_launch": int(dom["flops"] / dom["launches"])}
+    if exact_value is not None:
+        res["value_pointwise_f16x3_float32_equivalent"] = round(exact_value, 1)
+    if per_layer and rank == 0:
+        for l, ms in zip(layers, layer_ms):
+            sp = l.spec
+            print(f"  {l.kernel:18s} {sp.c_in:4d}->{sp.c_out:4d} k{sp.k[0]} s{sp.stride[0]} {sp.h:3d}->{sp.h_out:3d}  "
+                  f"{ms:8.4f} ms  {l.bytes / ms / 1e6:8.1f} GB/s", file=sys.stderr)
+    del layers
+    torch.cuda.empty_cache()
+    return res, rank_dts
+
+
+def codec_bench(L, dev, n=1 << 28, reps=5):
+    """the standalone codec as a bandwidth kernel -- slfp_quantize_f32 (4 B in + 4 B out per
+    element) and slfp_encode_f32 (4 B in + 1 B out) on 1 GiB of float32, HIP events on the launch stream."""
+    x = torch.randn(n, device=dev).abs_().mul_(2.0)
+    y = torch.empty_like(x)
+    c = torch.empty(n, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    out = {"elements": n}
+    for name, fn, bpe in (("quantize_act8", lambda: L.slfp_quantize_f32(x.data_ptr(), y.data_ptr(), n, 0.17, _lib.FMT_ACT8, stream), 8),
+                          ("encode_act8", lambda: L.slfp_encode_f32(x.data_ptr(), c.data_ptr(), n, 0.17, _lib.FMT_ACT8, stream), 5),
+                          ("quantize_sfp7", lambda: L.slfp_quantize_f32(x.data_ptr(), y.data_ptr(), n, 0.17, _lib.FMT_SFP7, stream), 8)):
+        _lib.check(fn())
+        torch.cuda.synchronize()
+        best = 1e9
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); _lib.check(fn()); e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1))
+        gbs = n * bpe / (best * 1e-3) / 1e9
+        out[name] = {"GB/s": round(gbs, 1), "frac_of_8TBs": round(gbs / HBM_PEAK_GBS, 4), "ms": round(best, 4), "bytes_per_element": bpe}
+    del x, y, c
+    torch.cuda.empty_cache()
+    return out
+
+
+# BASELINE.json configs 3-5 at their named batch sizes (config 4: the per-GPU slice of global batch 1024 on 8 GPUs)
+OTHER_CONFIGS = (("vgg16_224", 128, 8), ("resnet50_imagenet224", 128, 8), ("squeezenet1_0_imagenet224", 256, 7),
+                 ("shufflenetv2_224", 256, 7))
 
 
 def main():
@@ -252,12 +438,16 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--net", default="mobilenetv1_imagenet224")
-    ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU per step (weak scaling)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="strong scaling: this many images per step in total, sharded over the ranks on the batch axis "
+                         "(BASELINE config 4: --net resnet50_imagenet224 --global-batch 1024)")
     ap.add_argument("--passes", type=int, default=0, choices=[0, 1, 3], help="pointwise MFMA precision (0 = library default)")
     ap.add_argument("--qbits", type=int, default=8, choices=[8, 7], help="8 = SLFP<3,4> (headline), 7 = SFP<3,3> (BASELINE config 5)")
     ap.add_argument("--post", action="store_true", help="run every layer with the fused BN+ReLU epilogue (secondary measurement)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-whole-net", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of BASELINE configs 3-5 and the codec")
     ap.add_argument("--cpu-sample-batch", type=int, default=16)
     ap.add_argument("--per-layer", action="store_true", help="also print a per-layer table to stderr")
     args = ap.parse_args()
@@ -284,141 +474,54 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    specs = layer_specs.conv_layers(args.net)
-    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    layers = [Layer(L, s, args.batch, dev, args.passes, gen, args.qbits, args.post) for s in specs]
-    stream = torch.cuda.current_stream().cuda_stream
+    lo, hi, strong = sharding.per_rank_batch(args.batch, args.global_batch, rank, world)   # this rank's slice of the batch
+    batch = hi - lo
+    if strong and batch * world != args.global_batch:
+        raise SystemExit("--global-batch must divide evenly over the ranks (the bench reports one per-rank batch)")
 
-    # quantize the weights ONCE on rank 0 and broadcast the prepared blobs as one bucket
-    # (batch-axis sharding: the only collective of the whole path, sharding.py)
-    if rank == 0:
-        for l in layers:
-            l.prepare(L, stream)
-    torch.cuda.synchronize()
-    if world > 1:
-        sharding.broadcast_blobs([l.blob for l in layers], src=0)
-        torch.cuda.synchronize()
-
-    def step():
-        for l in layers:
-            l.run(L, stream)
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    # ---- per-kernel timing with HIP events on the launch stream (separate pass) ----
-    ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in layers]
-          for _ in range(args.steps)]
-    for k in range(args.steps):
-        for i, l in enumerate(layers):
-            ev[k][i][0].record()
-            l.run(L, stream)
-            ev[k][i][1].record()
-    torch.cuda.synchronize()
-    layer_ms = [float(np.mean([ev[k][i][0].elapsed_time(ev[k][i][1]) for k in range(args.steps)])) for i in range(len(layers))]
-    fam = {}
-    for l, ms in zip(layers, layer_ms):
-        f = fam.setdefault(l.kernel, {"ms": 0.0, "bytes": 0, "launches": 0, "flops": 0})
-        f["ms"] += ms
-        f["bytes"] += l.bytes
-        f["flops"] += 2 * l.spec.macs * l.batch
-        f["launches"] += 1
-    dominant = max(fam, key=lambda k: fam[k]["ms"])
-    dom = fam[dominant]
-    dom_gbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
-
-    # ---- the float32-equivalent pointwise mode (fp16 hi/lo split, 3 MFMA passes), same buffers
-    exact_value = None
-    if args.passes == 0 and args.qbits == 8:
-        for l in layers:
-            l.set_passes(L, stream, _lib.MFMA_F16X3)
-        step()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        dte = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dte], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dte = float(t.item())
-        exact_value = args.batch * world * args.steps / dte
-        for l in layers:
-            l.set_passes(L, stream, args.passes)
+    res, rank_dts = run_config(L, args.net, batch, args.qbits, args.passes, args.steps, args.warmup, dev, rank, world,
+                               post=args.post, per_layer=args.per_layer, exact_too=True)
 
     if rank == 0:
-        imgs = args.batch * world * args.steps
-        value = imgs / dt
-        bytes_img = layer_specs.algorithmic_bytes_per_image(args.net, args.batch)
-        whole_gbs = bytes_img * value / 1e9 / world  # per GPU
         out = {
             "metric": "images/sec at batch 256, MobileNetV1 SLFP<3,4> ImageNet-224; % HBM roofline",
-            "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "value": res["value"], "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32 (1x1 contraction: fp16 MFMA operands, f32 accumulate)", "data": "synthetic",
-            "config": {"workload": f"{args.net}: all {len(layers)} Conv2d_Q layers, "
+            "config": {"workload": f"{args.net}: all {res['n_layers']} Conv2d_Q layers, "
                                    f"{'SLFP<3,4> Qbits=8' if args.qbits == 8 else 'SFP<3,3> Qbits=7'}, NHWC, "
-                                   f"batch {args.batch} per GPU, inputs resident in HBM",
-                       "batch_per_gpu": args.batch, "global_batch": args.batch * world,
-                       "parallelism": f"batch-sharded x{world}, one-time RCCL weight broadcast",
-                       "pointwise_mfma": next((l.kernel for l in layers if l.kernel.startswith("pw_")), None)},
-            "hbm_roofline_frac_whole_path": round(whole_gbs / HBM_PEAK_GBS, 4),
-            "algorithmic_bytes_per_image": int(bytes_img),
-            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(dom_gbs, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(dom_gbs / HBM_PEAK_GBS, 4),
-                         "frac_of_measured_copy_ceiling": round(dom_gbs / HBM_COPY_GBS, 4),
-                         "traffic": pmc_traffic(dominant, args.net, args.batch)[0],
-                         "traffic_profile": pmc_traffic(dominant, args.net, args.batch)[1],
-                         "launches_per_step": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
-                         "algorithmic_bytes_per_launch": int(dom["bytes"] / dom["launches"])},
-            "kernels": {k: {"ms_per_step": round(v["ms"], 4), "GB/s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
-                            "TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1), "launches": v["launches"]}
-                        for k, v in fam.items()},
+                                   f"batch {batch} per GPU, inputs resident in HBM",
+                       "batch_per_gpu": batch, "global_batch": batch * world,
+                       "parallelism": f"batch-sharded x{world}, one-time RCCL broadcast of the u8 weight codes",
+                       "pointwise_mfma": res["pointwise_mfma"]},
+            "hbm_roofline_frac_whole_path": res["hbm_roofline_frac_whole_path"],
+            "algorithmic_bytes_per_image": res["algorithmic_bytes_per_image"],
+            "roofline": res["roofline"], "kernels": res["kernels"],
+            "rank_ms_per_step": [round(d / args.steps * 1e3, 4) for d in rank_dts],
         }
-        if dominant.startswith(("dense_mfma", "stem_mfma_")):
-            # compute-bound families (VGG-16 / ResNet-50 3x3, large stems): price against the matrix cores.
-            # achieved = algorithmic flops (2 * MACs of the layers) / measured time incl. the fp16 encode pre-pass
-            tf = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": dominant, "achieved": round(tf, 1), "peak": MFMA_F16_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": round(tf / MFMA_F16_PEAK_TFLOPS, 4), "traffic": None,
-                               "launches_per_step": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
-                               "algorithmic_flops_per_launch": int(dom["flops"] / dom["launches"])}
-        if exact_value is not None:
-            out["value_pointwise_f16x3_float32_equivalent"] = round(exact_value, 1)
-        if args.per_layer:
-            for l, ms in zip(layers, layer_ms):
-                s = l.spec
-                print(f"  {l.kernel:18s} {s.c_in:4d}->{s.c_out:4d} k{s.k[0]} s{s.stride[0]} {s.h:3d}->{s.h_out:3d}  "
-                      f"{ms:8.4f} ms  {l.bytes / ms / 1e6:8.1f} GB/s", file=sys.stderr)
-        if world == 1 and not args.no_whole_net:
-            del layers  # free the per-layer workload buffers first
-            torch.cuda.empty_cache()
-            wn = whole_net(specs, args.net, args.batch, dev, max(3, args.steps // 2))
+        if "value_pointwise_f16x3_float32_equivalent" in res:
+            out["value_pointwise_f16x3_float32_equivalent"] = res["value_pointwise_f16x3_float32_equivalent"]
+    if world == 1 and rank == 0:
+        if not args.no_other_configs:
+            # BASELINE configs 3-5 at their named batch sizes: short runs (3 steps), each with its own roofline object
+            other = {}
+            for net, b, q in OTHER_CONFIGS:
+                try:
+                    r, _ = run_config(L, net, b, q, 0, 3, 1, dev, 0, 1)
+                    other[net] = {"batch": b, "qbits": q, "value": r["value"], "unit": "images/sec", "ms_per_step": r["ms_per_step"],
+                                  "hbm_roofline_frac_whole_path": r["hbm_roofline_frac_whole_path"], "roofline": r["roofline"],
+                                  "kernels": r["kernels"]}
+                except Exception as e:  # a secondary measurement must not take the headline line down
+                    other[net] = {"batch": b, "qbits": q, "error": str(e)[:200]}
+            out["other_configs"] = other
+            out["codec"] = codec_bench(L, dev)
+        if not args.no_whole_net:
+            wn = whole_net(layer_specs.conv_layers(args.net), args.net, batch, dev, max(3, args.steps // 2))
             if wn:
                 out["whole_net"] = wn
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(specs, args.cpu_sample_batch, 1)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(layer_specs.conv_layers(args.net), args.cpu_sample_batch, 1)
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -20,7 +20,7 @@ SYMBOLS = (
     "slfp_version", "slfp_last_error", "slfp_device_count",
     "slfp_encode_f32", "slfp_decode_f32", "slfp_quantize_f32", "slfp_quantize_layerout_f32", "slfp_absmax_f32",
     "slfp_conv2d_out_shape", "slfp_conv2d_kernel_name", "slfp_conv2d_wprep_bytes",
-    "slfp_conv2d_prepare_weights", "slfp_conv2d_workspace_bytes", "slfp_conv2d_fwd", "slfp_conv2d_fwd_post",
+    "slfp_conv2d_prepare_weights", "slfp_conv2d_prepare_weights_codes", "slfp_conv2d_workspace_bytes", "slfp_conv2d_fwd", "slfp_conv2d_fwd_post",
     "slfp_linear_workspace_bytes", "slfp_linear_fwd", "slfp_linear_prepare_weights", "slfp_linear_fwd_prepared",
     "slfp_nchw_to_nhwc_f32", "slfp_nhwc_to_nchw_f32", "slfp_debug_div_mismatches",
     "slfp_debug_enc_mismatches", "slfp_enc_table_ok",
@@ -74,6 +74,7 @@ def load():
         "slfp_conv2d_kernel_name": (ctypes.c_char_p, [dp]),
         "slfp_conv2d_wprep_bytes": (sz, [dp]),
         "slfp_conv2d_prepare_weights": (ci, [dp, vp, vp, vp, vp]),
+        "slfp_conv2d_prepare_weights_codes": (ci, [dp, vp, vp, vp, vp]),
         "slfp_conv2d_workspace_bytes": (sz, [dp]),
         "slfp_conv2d_fwd": (ci, [dp, vp, vp, vp, vp, vp, vp, vp]),
         "slfp_conv2d_fwd_post": (ci, [dp, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp]),

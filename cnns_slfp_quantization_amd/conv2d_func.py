@@ -9,10 +9,17 @@ Drop-in operator API (same names, positional order, attributes and state-dict ke
 Where the reference runs  x/Ka -> ~25-pass quantize_act -> w/Kw -> ~25-pass
 quantize_weight (every forward) -> fp32 F.conv2d -> *Ka*Kw  (conv2d_func.py:20-25), this
 module makes ONE call into libslfp_hip.so (slfp_conv2d_fwd): the SLFP encode is applied
-inline on the kernels' load path, weights are quantized once per weight version into a
-kernel-specific blob (cache invalidated exactly on `weight._version` / storage change),
-and `input_q` / `weight_q` -- which the CIFAR nets read back after every forward
-(nets_cifar/mobilenetv1.py:88-171) -- are materialised lazily on first access.
+inline on the kernels' load path; `input_q` / `weight_q` -- which the CIFAR nets read back
+after every forward (nets_cifar/mobilenetv1.py:88-171) -- are materialised lazily on first
+access.
+
+Weights: the reference re-quantizes them on EVERY forward (utils/conv2d_func.py:22).  So does
+this module whenever the weights can change under it: in training mode, and whenever autograd
+is recording -- the reference's own optimizers update `p.data` in place (utils/optimizer.py:
+58-63), which does not bump `weight._version`, so no version key can see it.  Only in
+inference (`module.eval()` and `torch.no_grad()`/`inference_mode`) is the kernel-specific
+weight blob cached, keyed on storage, `_version`, shape, scales and kernel; every
+`module.train(...)` / `.eval()` call and `invalidate()` drop it.
 
 Memory layout: the kernels are NHWC.  A `torch.channels_last` input is consumed and
 produced in place (zero copies; BN/ReLU keep the format); an NCHW-contiguous input is
@@ -77,10 +84,15 @@ class _PreparedWeights:
         self.blob = None
         self.weight_q = None
 
-    def get(self, L, desc, weight, want_weight_q):
+    def invalidate(self):
+        self.key = None
+        self.blob = None
+        self.weight_q = None
+
+    def get(self, L, desc, weight, want_weight_q, cache=True):
         key = (weight.device, weight.data_ptr(), weight._version, tuple(weight.shape), desc.qbits,
                desc.kw_scale, L.slfp_conv2d_kernel_name(ctypes.byref(desc)))
-        if key != self.key or self.blob is None or (want_weight_q and self.weight_q is None):
+        if not cache or key != self.key or self.blob is None or (want_weight_q and self.weight_q is None):
             nbytes = L.slfp_conv2d_wprep_bytes(ctypes.byref(desc))
             w = weight.detach()
             w = w if w.is_contiguous() else w.contiguous()  # OIHW
@@ -93,8 +105,9 @@ class _PreparedWeights:
         return self.blob
 
 
-def _hip_conv2d(mod, x, weight, bias):
-    """One slfp_conv2d_fwd call for module `mod` (an nn.Conv2d subclass below)."""
+def _hip_conv2d(mod, x, weight, bias, cache_ok=False):
+    """One slfp_conv2d_fwd call for module `mod` (an nn.Conv2d subclass below).  cache_ok: the prepared weights may
+    come from the module's cache (decided by the caller: grad mode is off inside autograd.Function.forward)."""
     _require_gpu_f32(x, "Conv2d_Q")
     if weight.device != x.device:
         raise RuntimeError(f"Conv2d_Q: input is on {x.device} but weight is on {weight.device}")
@@ -126,7 +139,8 @@ def _hip_conv2d(mod, x, weight, bias):
     ho, wo = ctypes.c_int64(), ctypes.c_int64()
     with torch.cuda.device(x.device):
         _lib.check(L.slfp_conv2d_out_shape(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)))
-        blob = mod._prep.get(L, d, weight, want_weight_q=options.eager_stash)
+        # cache the prepared weights only where they cannot change unseen: inference (see the module docstring)
+        blob = mod._prep.get(L, d, weight, want_weight_q=options.eager_stash, cache=cache_ok)
         y = torch.empty((N, mod.out_channels, ho.value, wo.value), dtype=torch.float32, device=x.device,
                         memory_format=torch.channels_last if nhwc_out else torch.contiguous_format)
         ws_bytes = L.slfp_conv2d_workspace_bytes(ctypes.byref(d))
@@ -237,10 +251,19 @@ def _conv_class(q_bit, Kw, Ka, bias_default, scaled_bias):
                 return self._weight_q32
             if self._last_input is None:
                 return None
-            if self._prep.weight_q is None or self._prep.key is None or self._prep.key[2] != self.weight._version:
+            stale = self._prep.weight_q is None or self._prep.key is None or self._prep.key[2] != self.weight._version
+            if stale or self.training or torch.is_grad_enabled():   # p.data updates are invisible to _version
                 fmt = _lib.FMT_W8 if self.q_bit == 8 else _lib.FMT_SFP7
                 self._prep.weight_q = hip_quantize(self.weight.detach().contiguous(), _f32(self.Kw), fmt)
             return self._prep.weight_q
+
+        def invalidate(self):
+            """Drop the cached quantized weights (call after changing `weight.data` in place during inference)."""
+            self._prep.invalidate()
+
+        def train(self, mode=True):
+            self._prep.invalidate()   # weights may have been stepped through `.data` since the last forward
+            return super(Conv2d_Q, self).train(mode)
 
         def forward(self, input, order=None):
             if self.q_bit == 32:
@@ -265,9 +288,11 @@ def _conv_class(q_bit, Kw, Ka, bias_default, scaled_bias):
             if self._post is not None and self.bias is not None and not scaled_bias:
                 raise NotImplementedError("fused epilogue with conv2d_Q's raw (unscaled) bias is not supported")
             if need_grad and self._post is None:
-                out = _SlfpConv2dFn.apply(input, self.weight, self.bias, self, scaled_bias)
+                # conv2d_Q's raw bias is added below, outside the Function: only the scaled one goes through it
+                out = _SlfpConv2dFn.apply(input, self.weight, self.bias if scaled_bias else None, self, scaled_bias)
             else:
-                out = _hip_conv2d(self, input, self.weight, self.bias if scaled_bias else None)
+                out = _hip_conv2d(self, input, self.weight, self.bias if scaled_bias else None,
+                                  cache_ok=not self.training and not torch.is_grad_enabled())
             if self.bias is not None and not scaled_bias:
                 # conv2d_Q hands the raw bias to F.conv2d (utils/conv2d_func.py:23): (conv + b)*Ka*Kw
                 out = out + (self.bias * self.Ka * self.Kw).to(out.dtype).view(1, -1, 1, 1)
@@ -287,7 +312,7 @@ def conv2d_Q_bias(q_bit, Kw, Ka):
     return _conv_class(q_bit, Kw, Ka, bias_default=True, scaled_bias=True)
 
 
-def _hip_linear(mod, x, weight, bias):
+def _hip_linear(mod, x, weight, bias, cache_ok=False):
     _require_gpu_f32(x, "Linear_Q")
     L = _lib.load()
     lead = x.shape[:-1]
@@ -311,7 +336,7 @@ def _hip_linear(mod, x, weight, bias):
         # dominant cost of their classifiers)
         key = (w.device, w.data_ptr(), weight._version, tuple(w.shape), mod.q_bit, kw, options.mfma_passes)
         cache = mod.__dict__.get("_lin_prep")
-        if cache is None or cache[0] != key:
+        if cache is None or cache[0] != key or not cache_ok:   # see the module docstring
             blob = torch.empty(max(L.slfp_linear_workspace_bytes(1, I, O), 16), dtype=torch.uint8, device=x.device)
             _lib.check(L.slfp_linear_prepare_weights(w.data_ptr(), blob.data_ptr(), I, O, kw, mod.q_bit,
                                                      options.mfma_passes, _stream_handle(x)))
@@ -360,22 +385,54 @@ def linear_Q(q_bit, Kw, Ka):
             self.quantize_act = act_quantize_func(q_bit=q_bit)
             self.Kw = torch.tensor(Kw)
             self.Ka = torch.tensor(Ka)
+            self._last_input = None
+            self._input_q = None
+            self._weight_q = None
+            self.bias_q = None
+
+        # The reference stores input_q / weight_q / bias_q on every forward (utils/conv2d_func.py:60-64) and its nets
+        # read them back afterwards (nets_cifar/mobilenetv1.py:169-170, resnet50.py:353-354, alexnet.py:107-114);
+        # here the two quantized tensors are computed on first access after a forward.
+        @property
+        def input_q(self):
+            if self.q_bit != 32 and self._input_q is None and self._last_input is not None:
+                fmt = _lib.FMT_ACT8 if self.q_bit == 8 else _lib.FMT_SFP7
+                self._input_q = hip_quantize(self._last_input, _f32(self.Ka), fmt)
+            return self._input_q
+
+        @property
+        def weight_q(self):
+            if self.q_bit != 32 and self._weight_q is None and self._last_input is not None:
+                fmt = _lib.FMT_W8 if self.q_bit == 8 else _lib.FMT_SFP7
+                self._weight_q = hip_quantize(self.weight.detach().contiguous(), _f32(self.Kw), fmt)
+            return self._weight_q
+
+        def invalidate(self):
+            self.__dict__.pop("_lin_prep", None)
+
+        def train(self, mode=True):
+            self.invalidate()
+            return super(Linear_Q, self).train(mode)
 
         def forward(self, input):
             if self.q_bit == 32:
-                self.input_q = input / self.Ka
-                self.weight_q = self.weight / self.Kw
+                self._input_q = input / self.Ka
+                self._weight_q = self.weight / self.Kw
                 # the reference dereferences self.bias unconditionally (utils/conv2d_func.py:63)
                 self.bias_q = self.bias / self.Kw / self.Ka
-                return F.linear(self.input_q, self.weight_q, self.bias_q) * self.Kw * self.Ka
+                return F.linear(self._input_q, self._weight_q, self.bias_q) * self.Kw * self.Ka
             if self.q_bit not in (8, 7):
                 raise UnboundLocalError("q_bit must be 32, 8 or 7 (utils/sfp_quant.py:142-147)")
             if self.bias is None:
                 raise TypeError("unsupported operand type(s) for /: 'NoneType' and 'Tensor'")  # as the reference
+            self._last_input = input.detach()
+            self._input_q = None
+            self._weight_q = None
+            self.bias_q = self.bias / self.Kw / self.Ka      # utils/conv2d_func.py:63 (the kernel applies the same two divisions)
             need_grad = torch.is_grad_enabled() and (input.requires_grad or self.weight.requires_grad or
                                                      self.bias.requires_grad)
             if need_grad:
                 return _SlfpLinearFn.apply(input, self.weight, self.bias, self)
-            return _hip_linear(self, input, self.weight, self.bias)
+            return _hip_linear(self, input, self.weight, self.bias, cache_ok=not self.training and not torch.is_grad_enabled())
 
     return Linear_Q

@@ -4,6 +4,9 @@
 // :59-97) by ONE HBM-bound pass: 16-byte loads, integer encode, 16-byte (or 4-byte code)
 // stores.  Roofline: 8 B/element (quantize) or 5 B/element (encode) of HBM traffic.
 #include <cstdarg>
+#include <mutex>
+#include <set>
+#include <utility>
 #include <cstdio>
 #include "slfp_device.hpp"
 #include "slfp_enc.hpp"
@@ -35,6 +38,21 @@ int check_launch(const char* what) {
 }
 
 const char* last_error_text() { return g_err; }
+
+int raise_lds_limit(const void* fn, size_t lds_bytes) {
+    if (lds_bytes <= 64 * 1024) return SLFP_OK;
+    static std::mutex mu;
+    static std::set<std::pair<int, const void*>> done;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return check_launch("hipGetDevice");
+    std::lock_guard<std::mutex> lock(mu);
+    const auto key = std::make_pair(dev, fn);
+    if (done.count(key)) return SLFP_OK;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        return check_launch("hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    done.insert(key);
+    return SLFP_OK;
+}
 
 constexpr int kThreads = 256;
 

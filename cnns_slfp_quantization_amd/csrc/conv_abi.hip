@@ -148,16 +148,21 @@ static int launch_repad(const float* src, float* dst, int64_t rows, int64_t cs, 
 
 // One thread per OIHW weight element: weight_q = QW(w / Kw) (utils/conv2d_func.py:22), written
 // in the layout the selected kernel family reads.
-template <int FMT>
+// CODES: `w` is not float32 weights but their 1-byte extended codes (slfp_encode_f32 with SLFP_FMT_EXT): the value is
+// decoded instead of quantized (decode(encode(x)) == quantize(x) bit for bit), so a blob built from broadcast codes
+// is identical to one built from the weights themselves (multi-GPU: sharding.py).
+template <int FMT, bool CODES = false>
 __global__ __launch_bounds__(256) void k_prepare(const float* __restrict__ w, void* __restrict__ prep,
                                                  float* __restrict__ wq_oihw, int64_t total, int O, int Cg, int KH,
                                                  int KW, const ScaleDiv sd, int family, int KS, int64_t plane, int ldo) {
     __shared__ uint32_t sT[16];
-    lut_fill<FMT>(sT);
+    lut_fill<FMT>(sT);   // W8 / SFP7: the identity table the decoder indexes as well
     __syncthreads();
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
-    const float q = quantize_scaled<FMT>(w[idx], sd, sT);
+    float q;
+    if constexpr (CODES) q = __uint_as_float(decode_bits<FMT>(reinterpret_cast<const uint8_t*>(w)[idx], true, sT));
+    else q = quantize_scaled<FMT>(w[idx], sd, sT);
     if (wq_oihw) wq_oihw[idx] = q;
     int64_t r = idx;
     const int kw = (int)(r % KW); r /= KW;
@@ -204,7 +209,7 @@ __global__ __launch_bounds__(256) void k_prepare(const float* __restrict__ w, vo
 }
 
 int launch_prepare_weights(const slfp_conv2d_desc& d, const ConvPlan& p, const float* w_oihw, void* wprep,
-                           float* weight_q_oihw, hipStream_t stream) {
+                           float* weight_q_oihw, hipStream_t stream, bool codes) {
     const int Cg = (int)(d.c_in / d.groups);
     const int64_t total = d.c_out * Cg * d.kh * d.kw;
     if (p.family == kPointwise || p.family == kDenseMfma || p.family == kStemMfma || p.family == kStemSmall || p.repad) {
@@ -216,12 +221,11 @@ int launch_prepare_weights(const slfp_conv2d_desc& d, const ConvPlan& p, const f
     const ScaleDiv sd = make_scale_div(d.kw_scale);
     // depthwise: row pitch of the [9][C] table (padded channel count); dense MFMA: 1 = also write the residual plane
     const int ldo = p.family == kDenseMfma ? (p.passes == 3 ? 1 : 0) : (int)p.cpo;
-    if (p.fmt_w == kFmtW8)
-        hipLaunchKernelGGL((k_prepare<kFmtW8>), dim3(grid), dim3(256), 0, stream, w_oihw, wprep, weight_q_oihw, total,
-                           (int)d.c_out, Cg, (int)d.kh, (int)d.kw, sd, (int)p.family, KS, plane, ldo);
-    else
-        hipLaunchKernelGGL((k_prepare<kFmtSfp7>), dim3(grid), dim3(256), 0, stream, w_oihw, wprep, weight_q_oihw, total,
-                           (int)d.c_out, Cg, (int)d.kh, (int)d.kw, sd, (int)p.family, KS, plane, ldo);
+#define SLFP_PREP(FF, CC) hipLaunchKernelGGL((k_prepare<FF, CC>), dim3(grid), dim3(256), 0, stream, w_oihw, wprep, weight_q_oihw, total, \
+                                             (int)d.c_out, Cg, (int)d.kh, (int)d.kw, sd, (int)p.family, KS, plane, ldo)
+    if (p.fmt_w == kFmtW8) { if (codes) SLFP_PREP(kFmtW8, true); else SLFP_PREP(kFmtW8, false); }
+    else { if (codes) SLFP_PREP(kFmtSfp7, true); else SLFP_PREP(kFmtSfp7, false); }
+#undef SLFP_PREP
     return check_launch("slfp weight prepare kernel");
 }
 
@@ -276,6 +280,16 @@ int slfp_conv2d_prepare_weights(const slfp_conv2d_desc* d, const float* w_oihw, 
     if (!w_oihw || !wprep) return fail(SLFP_ERR_BAD_ARG, "slfp_conv2d_prepare_weights: null pointer");
     if (!aligned16(wprep)) return fail(SLFP_ERR_ALIGNMENT, "slfp_conv2d_prepare_weights: wprep must be 16-byte aligned");
     return launch_prepare_weights(*d, p, w_oihw, wprep, weight_q_oihw, as_stream(stream));
+}
+
+int slfp_conv2d_prepare_weights_codes(const slfp_conv2d_desc* d, const uint8_t* codes_oihw, void* wprep, float* weight_q_oihw,
+                                      void* stream) {
+    ConvPlan p;
+    const int rc = make_plan(d, &p);
+    if (rc != SLFP_OK) return rc;
+    if (!codes_oihw || !wprep) return fail(SLFP_ERR_BAD_ARG, "slfp_conv2d_prepare_weights_codes: null pointer");
+    if (!aligned16(wprep)) return fail(SLFP_ERR_ALIGNMENT, "slfp_conv2d_prepare_weights_codes: wprep must be 16-byte aligned");
+    return launch_prepare_weights(*d, p, reinterpret_cast<const float*>(codes_oihw), wprep, weight_q_oihw, as_stream(stream), true);
 }
 
 size_t slfp_conv2d_workspace_bytes(const slfp_conv2d_desc* d) {

@@ -342,12 +342,8 @@ size_t dense_mfma_workspace_bytes(const slfp_conv2d_desc& d, int passes) {
 template <int WM, int WN, int MT, int PASSES>
 static int launch_dense_tp(DenseParams& p, size_t lds, hipStream_t stream) {
     auto fn = k_dense_mfma<WM, WN, MT, PASSES>;
-    static bool lds_raised = false;  // > 64 KiB of dynamic LDS needs the opt-in once per kernel
-    if (!lds_raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return check_launch("hipFuncSetAttribute(dense)");
-        lds_raised = true;
-    }
+    const int rc = raise_lds_limit(reinterpret_cast<const void*>(fn), 160 * 1024);  // once per (device, kernel)
+    if (rc != SLFP_OK) return rc;
     hipLaunchKernelGGL(fn, dim3(p.nblocks), dim3(kDnThreads), lds, stream, p);
     return check_launch("slfp dense MFMA conv kernel");
 }

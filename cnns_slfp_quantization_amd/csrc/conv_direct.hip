@@ -9,6 +9,7 @@
 // register tile and reads its weights (prepared as [KH][KW][C_in/g][C_out], 16-byte
 // loads, broadcast through L1) straight from global memory.
 #include "slfp_device.hpp"
+#include "slfp_enc.hpp"
 #include "slfp_host.hpp"
 
 namespace slfp {
@@ -157,6 +158,7 @@ struct StemParams {
     float s1, s2;
     PostOp post;
     uint32_t nblocks;
+    EncArgs enc;         // threshold table of QA(x / Ka) (k_stem_fixed<.., TAB>; slfp_enc.hpp)
 };
 
 template <int FMT>
@@ -263,7 +265,9 @@ __global__ __launch_bounds__(256) void k_stem(const float* __restrict__ x, const
 // Fully specialised stem (compile-time KH, KW, C, stride, O): every LDS address is base +
 // immediate, the 27 (or 147) taps unroll into ds_read + packed FMAs with no index arithmetic
 // (the generic k_stem was VALU-bound: 1225 instructions per wave, profiles/r01c).
-template <int FMT, int KH, int KW, int C, int S, int O>
+// TAB: threshold-table quantizer (slfp_enc.hpp) and branch-free halo loads: a buffer descriptor over the image makes
+// out-of-image elements an out-of-range offset that reads 0, so the 7 loads of a thread issue back to back.
+template <int FMT, int KH, int KW, int C, int S, int O, bool TAB = false>
 __global__ __launch_bounds__(256) void k_stem_fixed(const float* __restrict__ x, const float* __restrict__ wq,
                                                     const float* __restrict__ bias, float* __restrict__ y,
                                                     const StemParams p) {
@@ -273,8 +277,9 @@ __global__ __launch_bounds__(256) void k_stem_fixed(const float* __restrict__ x,
     static_assert(GROUPS % kStemTW == 0 && P >= 1 && NW % 4 == 0, "unsupported stem shape");
     __shared__ __attribute__((aligned(16))) float sW[NW];
     __shared__ __attribute__((aligned(16))) float tile[IH * IWC];
-    __shared__ uint32_t sT[16];
-    lut_fill<FMT>(sT);
+    __shared__ __attribute__((aligned(16))) uint32_t sT[TAB ? 2 * (kEncEntries + 1) : 16];
+    if constexpr (TAB) enc_fill<256>(reinterpret_cast<uint2*>(sT), p.enc);
+    else lut_fill<FMT>(sT);
     for (int i = threadIdx.x * 4; i < NW; i += 256 * 4)
         *reinterpret_cast<float4*>(sW + i) = *reinterpret_cast<const float4*>(wq + i);
 
@@ -290,19 +295,43 @@ __global__ __launch_bounds__(256) void k_stem_fixed(const float* __restrict__ x,
         const float* xn = x + (size_t)n * p.H * p.W * C;
         const int j_lo = -w_in0 * C, j_hi = (p.W - w_in0) * C;
         float v[U];
+        if constexpr (TAB) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xn), 0, (uint32_t)p.H * p.W * C * 4u, 0x00020000);
+            uint32_t vo[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int idx = threadIdx.x + u * 256;
-            const int ih = idx / IWC, j = idx - ih * IWC;  // compile-time divisor
-            const int gh = h_in0 + ih;
-            v[u] = 0.f;
-            if (idx < N_IN && (unsigned)gh < (unsigned)p.H && j >= j_lo && j < j_hi)
-                v[u] = xn[(gh * p.W + w_in0) * C + j];
-        }
+            for (int u = 0; u < U; ++u) {
+                const int idx = threadIdx.x + u * 256;
+                const int ih = idx / IWC, j = idx - ih * IWC;  // compile-time divisor
+                const int gh = h_in0 + ih;
+                const bool ok = idx < N_IN && (unsigned)gh < (unsigned)p.H && j >= j_lo && j < j_hi;
+                vo[u] = ok ? (uint32_t)((gh * p.W + w_in0) * C + j) * 4u : 0xFFFFFFF0u;
+                asm volatile("" : "+v"(vo[u]));
+            }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int idx = threadIdx.x + u * 256;
-            if (idx < N_IN) tile[idx] = quantize_scaled<FMT>(v[u], p.sd, sT);
+            for (int u = 0; u < U; ++u) v[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vo[u], 0, 0));
+            const unsigned char* tb = reinterpret_cast<const unsigned char*>(sT);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = threadIdx.x + u * 256;
+                float q = enc_f32(v[u], p.enc.r1, p.enc.lo, p.enc.hi, tb);
+                q = v[u] != v[u] ? __uint_as_float(kBitsQNaN) : q;   // NaN in -> NaN out
+                if (idx < N_IN) tile[idx] = q;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = threadIdx.x + u * 256;
+                const int ih = idx / IWC, j = idx - ih * IWC;  // compile-time divisor
+                const int gh = h_in0 + ih;
+                v[u] = 0.f;
+                if (idx < N_IN && (unsigned)gh < (unsigned)p.H && j >= j_lo && j < j_hi)
+                    v[u] = xn[(gh * p.W + w_in0) * C + j];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = threadIdx.x + u * 256;
+                if (idx < N_IN) tile[idx] = quantize_scaled<FMT>(v[u], p.sd, sT);
+            }
         }
     }
     __syncthreads();
@@ -405,7 +434,10 @@ static int try_launch_stem(const slfp_conv2d_desc& d, const ConvPlan& plan, cons
     p.nblocks = (uint32_t)nblocks;
     if (p.KH == 3 && p.KW == 3 && C == 3 && p.s == 2 && O == 32 && (int64_t)p.H * p.W * C < (1ll << 30)) {
         // the MobileNetV1 stem (nets_imgnet/mobilenetv1.py:44): fully specialised variant
-        if (plan.fmt_act == kFmtAct8)
+        if (const EncArgs* t = act_table(d.ka, plan.fmt_act, kEncF32)) {
+            p.enc = *t;
+            hipLaunchKernelGGL((k_stem_fixed<kFmtAct8, 3, 3, 3, 2, 32, true>), dim3(p.nblocks), dim3(256), 0, stream, x, wq_hwio, bias, y, p);
+        } else if (plan.fmt_act == kFmtAct8)
             hipLaunchKernelGGL((k_stem_fixed<kFmtAct8, 3, 3, 3, 2, 32>), dim3(p.nblocks), dim3(256), 0, stream, x, wq_hwio, bias, y, p);
         else
             hipLaunchKernelGGL((k_stem_fixed<kFmtSfp7, 3, 3, 3, 2, 32>), dim3(p.nblocks), dim3(256), 0, stream, x, wq_hwio, bias, y, p);

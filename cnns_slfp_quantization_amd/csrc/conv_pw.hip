@@ -506,13 +506,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 4) void k_pw_til
 
 
 // ---------------------------------------------------------------------------- launch
-static int set_lds_limit(const void* fn, size_t lds) {
-    if (lds > 64 * 1024) {
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return check_launch("hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
-    }
-    return SLFP_OK;
-}
+// once per (device, kernel), not per launch (round 1 re-armed the attribute on every launch)
+static int set_lds_limit(const void* fn, size_t lds) { return raise_lds_limit(fn, lds); }
 
 template <int FMT, int PASSES, int WM, int WN, int MT, int NT, bool KFULL>
 static int launch_tiled_k(PwParams& p, hipStream_t stream) {

@@ -194,12 +194,8 @@ size_t stem_mfma_workspace_bytes(const slfp_conv2d_desc& d, int64_t w_out) {
 template <int NT>
 static int launch_stem_mfma_t(const StemMfmaParams& p, size_t lds, unsigned grid, hipStream_t stream) {
     auto fn = k_stem_mfma<NT, 8>;
-    static bool lds_raised = false;
-    if (!lds_raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return check_launch("hipFuncSetAttribute(stem_mfma)");
-        lds_raised = true;
-    }
+    const int rc = raise_lds_limit(reinterpret_cast<const void*>(fn), 160 * 1024);  // once per (device, kernel)
+    if (rc != SLFP_OK) return rc;
     hipLaunchKernelGGL(fn, dim3(grid), dim3(kSmThreads), lds, stream, p);
     return check_launch("slfp MFMA stem kernel");
 }

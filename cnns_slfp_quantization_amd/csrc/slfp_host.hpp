@@ -18,6 +18,11 @@ int fail(int code, const char* fmt, ...);
 // Returns SLFP_OK or SLFP_ERR_HIP (and records the HIP error string) after a launch.
 int check_launch(const char* what);
 
+// Kernels that need more than 64 KiB of dynamic LDS must opt in with hipFuncSetAttribute.  The attribute belongs to the
+// (device, function) pair, so it is set once per pair, under a lock (any host thread may call the library; one process
+// may drive several devices).  Returns SLFP_OK or an error status.
+int raise_lds_limit(const void* fn, size_t lds_bytes);
+
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
@@ -96,8 +101,9 @@ bool dense_mfma_applicable(const slfp_conv2d_desc& d, int passes);
 size_t dense_mfma_workspace_bytes(const slfp_conv2d_desc& d, int passes);
 int launch_dense_mfma(const slfp_conv2d_desc& d, const ConvPlan& p, const float* x, const void* wblob,
                       const float* bias, const PostOp& post, float* y, void* workspace, hipStream_t stream);
+// codes: `w_oihw` points at 1-byte extended weight codes (slfp_encode_f32 | SLFP_FMT_EXT) instead of float32 weights
 int launch_prepare_weights(const slfp_conv2d_desc& d, const ConvPlan& p, const float* w_oihw, void* wprep,
-                           float* weight_q_oihw, hipStream_t stream);
+                           float* weight_q_oihw, hipStream_t stream, bool codes = false);
 
 // large-kernel image stems on MFMA (conv_stem_mfma.hip); wblob = [kh*ksub + sub][nt][64][8] fp16;
 // `workspace` receives the im2row'ed, encoded input

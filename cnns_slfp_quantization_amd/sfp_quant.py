@@ -15,9 +15,9 @@ it; backward is the reference's straight-through estimator (:50-53, :99-102).  T
 require ROCm ("cuda") float32 tensors: there is no CPU compute path in this package (the
 CPU checker is oracle/, test-only).  k == 32 is the identity (:11-12, :60-61).
 
-quantize_layerout (SFP<4,4> output quantizer, :105-133) is a "next" row of SURVEY 8(f):
-it is provided here as a plain-PyTorch composite restatement (any device) so that the
-nets that instantiate it construct and run; it is not on the accelerated path yet.
+quantize_layerout (SFP<4,4> output quantizer, :105-133) runs on the device as well
+(slfp_quantize_layerout_f32, bit-identical including the reference's XOR quirks) and can be
+fused into the conv epilogue by fusion.fuse_bn_relu; like every quantized op it needs a ROCm tensor.
 """
 import numpy as np
 import torch

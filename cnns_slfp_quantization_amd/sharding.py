@@ -6,7 +6,10 @@ units through the whole hot path, so the MI355X design is: one process per GPU
 of the batch, and the ONLY collective is a one-time broadcast of the quantized (prepared)
 weight blobs from rank 0 -- all layers flattened into one bucket so that it is a single
 large RCCL broadcast instead of 27-53 small ones.  There is no per-step exchange.
-The same code runs on CPU tensors with the gloo backend (tests).
+What travels is the weights' u8 codes (1 B per weight, SURVEY 8e: 3.19 MB for MobileNetV1,
+23.5 MB for ResNet-50); every rank lays them out for its own kernels
+(slfp_conv2d_prepare_weights_codes).  The same code runs on CPU tensors with the gloo backend (tests);
+bench.py's N > 1 control flow is exactly these functions: per_rank_batch, broadcast_blobs, rank_times.
 """
 import torch
 import torch.distributed as dist
@@ -50,3 +53,23 @@ def gather_outputs(local, group=None):
     parts = [torch.empty_like(local) for _ in range(dist.get_world_size(group))]
     dist.all_gather(parts, local.contiguous(), group=group)
     return torch.cat(parts, dim=0)
+
+
+def per_rank_batch(batch, global_batch, rank, world):
+    """Images this rank processes per step: `batch` (weak scaling) or its contiguous slice of `global_batch`
+    (strong scaling, BASELINE config 4: 1024 -> 128 per GPU on 8 GPUs).  Returns (lo, hi, strong)."""
+    if global_batch and global_batch > 0:
+        lo, hi = shard_range(global_batch, rank, world)
+        return lo, hi, True
+    return rank * batch, (rank + 1) * batch, False
+
+
+def rank_times(seconds, device=None, group=None):
+    """Every rank's timed-region seconds, on every rank: the job's time is the MAX (the slowest rank), and the
+    rank-0 line reports all of them."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return [float(seconds)]
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    parts = [torch.zeros_like(t) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(parts, t, group=group)
+    return [float(p.item()) for p in parts]

@@ -108,6 +108,12 @@ size_t slfp_conv2d_wprep_bytes(const slfp_conv2d_desc* d);
  * whenever the weight tensor changes. */
 int slfp_conv2d_prepare_weights(const slfp_conv2d_desc* d, const float* w_oihw, void* wprep,
                                 float* weight_q_oihw, void* stream);
+/* The same blob from the weights' 1-byte codes: codes_oihw[i] = slfp_encode_f32(w, Kw, fmt | SLFP_FMT_EXT)[i] with fmt =
+ * SLFP_FMT_W8 (qbits 8) or SLFP_FMT_SFP7 (qbits 7).  decode(encode(x)) == quantize(x) bit for bit, so the blob is
+ * identical to slfp_conv2d_prepare_weights' -- this is what a rank builds from the broadcast of SURVEY 8(e)
+ * (quantized weights travel as u8 codes, 1 B per weight; each rank lays them out for its own kernels). */
+int slfp_conv2d_prepare_weights_codes(const slfp_conv2d_desc* d, const uint8_t* codes_oihw, void* wprep,
+                                      float* weight_q_oihw, void* stream);
 /* Bytes of scratch slfp_conv2d_fwd needs for this descriptor: 0 for the HBM-bound NHWC families
  * (depthwise, pointwise, 3x3 stems); non-zero when a layout conversion is involved and for the
  * two MFMA families of compute-bound layers ("dense_mfma_*": k x k with C_in >= 16,

@@ -102,12 +102,16 @@ def main():
                     row[a] = round(c[b] / wc, 3)
         if "SQ_LDS_IDX_ACTIVE" in c and c.get("SQ_LDS_BANK_CONFLICT") is not None and c["SQ_LDS_IDX_ACTIVE"] > 0:
             row["lds_conflict_frac"] = round(c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"], 3)
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in c and c.get("GRBM_GUI_ACTIVE", 0) > 0:
+            # matrix-core utilisation: MFMA-busy cycles summed over the 1024 SIMDs / (1024 x chip cycles); GRBM_GUI_ACTIVE
+            # is the sum over the 8 XCDs (MI355X_MICROARCH.md, DVFS give-back)
+            row["mfma_busy_frac"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * c["GRBM_GUI_ACTIVE"] / 8), 4)
         if "SQ_INSTS_VALU" in c and "SQ_WAVES" in c and c["SQ_WAVES"] > 0:
             row["valu_insts_per_wave"] = round(c["SQ_INSTS_VALU"] / c["SQ_WAVES"], 1)
         rows.append(row)
     json.dump(rows, open(os.path.join(ROOT, "profiles", f"{tag}_summary.json"), "w"), indent=1)
     cols = ["kernel", "grid_threads", "launches", "avg_us", "vgpr", "agpr", "lds", "hbm_read_MB", "hbm_write_MB", "hbm_GBps",
-            "valu_active_frac", "wait_any_frac", "lds_conflict_frac", "valu_insts_per_wave"]
+            "valu_active_frac", "wait_any_frac", "lds_conflict_frac", "mfma_busy_frac", "valu_insts_per_wave"]
     with open(os.path.join(ROOT, "profiles", f"{tag}_summary.md"), "w") as f:
         f.write(f"# rocprofv3 summary `{tag}` (bench.py, {what}, 1x MI355X)\n\n")
         f.write("Source: `profiles/run_profile.sh` (kernel-trace --stats pass + separate --pmc passes). "

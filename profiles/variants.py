@@ -5,7 +5,9 @@
 
 Times every layer of the chosen kernel family (MobileNetV1-224, batch 256 by default) with HIP events, for the
 default library behaviour and for each --var setting, in interleaved rounds (cdna guide rule 24: one process, one
-device), and prints median microseconds and algorithmic GB/s.  Only switches that the library reads at launch time
+device), and prints median microseconds and algorithmic GB/s.  Within a round the layers run ONCE each, in order, like a
+bench.py step: a layer that is launched several times back to back finds its 100-200 MB of input and output in the
+256 MiB Infinity Cache and looks 20-25 % faster than it is in the net (--warm restores that behaviour).  Only switches that the library reads at launch time
 work here (SLFP_DW_OLD, SLFP_DW_ABLATE, SLFP_PW_*); SLFP_LONG_ENCODE is read once per process (use ab_env.sh).
 """
 import argparse
@@ -30,6 +32,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--passes", type=int, default=1)
     ap.add_argument("--post", action="store_true")
+    ap.add_argument("--warm", action="store_true", help="3 back-to-back launches per layer (Infinity-Cache-warm numbers)")
     ap.add_argument("--layers", default="", help="comma-separated indices into the family's layers (default all)")
     args = ap.parse_args()
     L = _lib.load()
@@ -50,15 +53,21 @@ def main():
             for k in keys:
                 os.environ.pop(k, None)
             os.environ.update(env)
+            reps = 3 if args.warm else 1
+            evs = []
             for i, l in enumerate(layers):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                for _ in range(3):
+                for _ in range(reps):
                     l.run(L, stream)
                 e1.record()
-                torch.cuda.synchronize()
-                if r:
-                    times[name][i].append(e0.elapsed_time(e1) / 3 * 1e3)
+                evs.append((e0, e1))
+                if args.warm:
+                    torch.cuda.synchronize()
+            torch.cuda.synchronize()
+            if r:
+                for i, (e0, e1) in enumerate(evs):
+                    times[name][i].append(e0.elapsed_time(e1) / reps * 1e3)
     print(f"{'layer':34s}" + "".join(f"{n:>26s}" for n, _ in variants))
     tot = {n: 0.0 for n, _ in variants}
     for i, l in enumerate(layers):

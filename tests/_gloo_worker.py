@@ -43,6 +43,22 @@ def main():
     t = torch.tensor([0.5 + 0.25 * rank], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     assert abs(float(t) - (0.5 + 0.25 * (world - 1))) < 1e-12
+    # 5. bench.py's N > 1 control flow, step by step, on CPU stand-ins: per-rank batch (weak and strong scaling), the
+    #    weights as u8 CODES (1 B per weight) broadcast in one bucket from rank 0, every rank's time on every rank
+    lo_w, hi_w, strong = sharding.per_rank_batch(256, 0, rank, world)
+    assert (lo_w, hi_w, strong) == (rank * 256, (rank + 1) * 256, False)
+    lo_s, hi_s, strong = sharding.per_rank_batch(256, 1024 * world, rank, world)   # BASELINE config 4's shape: G / world each
+    assert strong and hi_s - lo_s == 1024 and lo_s == rank * 1024
+    g2 = torch.Generator().manual_seed(11)
+    codes_want = [torch.randint(0, 256, (s.w_elems,), dtype=torch.uint8, generator=g2) for s in specs]   # 1 B per weight
+    assert sum(int(c.numel()) for c in codes_want) == sum(s.w_elems for s in specs) == 3185088        # 3.19 MB
+    codes = [c.clone() if rank == 0 else torch.empty_like(c) for c in codes_want]
+    sharding.broadcast_blobs(codes, src=0)
+    assert all(torch.equal(a, b) for a, b in zip(codes, codes_want))
+    times = sharding.rank_times(0.01 * (rank + 1))
+    assert len(times) == world and all(abs(times[r] - 0.01 * (r + 1)) < 1e-12 for r in range(world))
+    value = 256 * world * 10 / max(times)      # whole-job images / slowest rank's seconds, as bench.py reports it
+    assert abs(value - 256 * world * 10 / (0.01 * world)) < 1e-6
     dist.barrier()
     dist.destroy_process_group()
     print(f"rank {rank} ok")
