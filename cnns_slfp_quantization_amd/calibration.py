@@ -102,8 +102,13 @@ def collect_max_abs(model, batches, total_images=1000):
     registration order, with the reference's definitions: input_q, the layer's output, weight_q."""
     layers = quantized_layers(model)
     run_in, run_out, run_w = {}, {}, {}
-    hooks = [mod.register_forward_hook(lambda m, a, out, i=i: (_update(run_in, i, m.input_q), _update(run_out, i, out)))
-             for i, mod in enumerate(layers)]
+    def make_hook(i):
+        def hook(m, args, out):   # returns None: a forward hook's return value would replace the module's output
+            _update(run_in, i, m.input_q)
+            _update(run_out, i, out)
+        return hook
+
+    hooks = [mod.register_forward_hook(make_hook(i)) for i, mod in enumerate(layers)]
     was_training = model.training
     model.eval()
     seen = 0

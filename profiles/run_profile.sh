@@ -4,7 +4,7 @@
 # into the committed profiles/*.md / *.json.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-r01}
-ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-whole-net --passes 1 ${2:-}"
+ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-whole-net --no-other-configs --passes 1 ${2:-}"
 cd /tmp && export TMPDIR=/tmp
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT

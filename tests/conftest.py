@@ -53,3 +53,22 @@ def rel_errors(y, ref):
     ref = np.asarray(ref, dtype=np.float64)
     d = y - ref
     return float(np.abs(d).max() / max(np.abs(ref).max(), 1e-30)), float(np.linalg.norm(d) / max(np.linalg.norm(ref), 1e-30))
+
+
+def elem_exceed_frac(y, ref, rel=1e-3):
+    """Fraction of elements with |y - ref| > rel * |ref| (elementwise, unlike rel_errors): a regression in small-magnitude
+    outputs is invisible to a tensor-relative metric.  Exact zeros of the reference count as exceeding only if y != 0."""
+    y = np.asarray(y, dtype=np.float64).ravel()
+    ref = np.asarray(ref, dtype=np.float64).ravel()
+    return float(np.mean(np.abs(y - ref) > rel * np.abs(ref)))
+
+
+# per kernel family: (elements compared, elements beyond the elementwise 1e-3 * |ref| bar); filled by the GPU parity tests
+ELEM_STATS = {}
+
+
+def note_elem_stats(kern, y, ref):
+    n = int(np.asarray(ref).size)
+    k = ELEM_STATS.setdefault(kern, [0, 0.0])
+    k[0] += n
+    k[1] += elem_exceed_frac(y, ref) * n

@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_errors, same_bits
+from conftest import ELEM_STATS, elem_exceed_frac, note_elem_stats, rel_errors, same_bits
 from oracle import slfp_oracle as so
 from oracle import torch_port as tp
 
@@ -326,6 +326,11 @@ def _check_against_oracle(lib, dev, N, C, H, O, k, s, p, g, qbits, passes, seed,
                                          and (C % 4 + O % 4 == 0 or (stream_fits and C >= 8)))
     emax, el2 = rel_errors(got, ref)
     assert emax <= tol and el2 <= tol, (kern, (N, C, H, O, k, s), emax, el2)
+    # elementwise view of the same comparison: fraction of outputs beyond 1e-3 * |ref|.  Float32-equivalent
+    # kernels: only cancellation noise near zero crossings; single-pass fp16 MFMA: SURVEY section 7 measured 14 %.
+    frac = elem_exceed_frac(got, ref)
+    note_elem_stats(kern, got, ref)
+    assert frac <= (0.30 if kern.endswith("_f16x1") else 0.02), (kern, (N, C, H, O, k, s), frac)
     return kern, emax, el2
 
 
@@ -1005,3 +1010,13 @@ def test_calibration_matches_reference_get_scale_factor(dev):
         assert mw[0] == float((m[0].weight.detach() / 2.0).abs().max())                  # weight_q = w / Kw
         assert abs(mo[1] - max(float(m(b).abs().max()) for b in batches[:3])) <= 1e-6 * mo[1]
     assert calibration.scales_from_max(mw)[0] == mw[0] / 15.5
+
+
+def test_zz_elementwise_error_fractions_per_kernel_family():
+    """Runs last in this file: the per-family fraction of outputs whose error exceeds 1e-3 * |ref| ELEMENTWISE, accumulated
+    over every oracle comparison above (DESIGN.md section 2 quotes these)."""
+    assert ELEM_STATS, "no oracle comparison ran before this test"
+    for kern, (n, bad) in sorted(ELEM_STATS.items()):
+        frac = bad / max(n, 1)
+        print(f"elementwise |d| > 1e-3 |ref|: {kern:28s} {frac:9.2e}  ({n} outputs)")
+        assert frac <= (0.25 if kern.endswith("_f16x1") else 5e-3), (kern, frac)
