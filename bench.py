@@ -176,9 +176,11 @@ def whole_net(specs, net, batch, dev, steps):
     x = torch.randn((batch, 3, 224, 224), device=dev, generator=g).contiguous(memory_format=torch.channels_last)
     out = {}
     with torch.no_grad():
-        for tag in ("stock_bn_relu", "fused_bn_relu"):
+        for tag in ("stock_bn_relu", "fused_bn_relu", "fused_dw_pw"):
             if tag == "fused_bn_relu":
                 fusion.fuse_bn_relu(model)
+            if tag == "fused_dw_pw":   # MobileNet blocks as ONE kernel each where libslfp_hip supports the pair (csrc/conv_dwpw.hip)
+                out["dw_pw_blocks_formed"] = fusion.fuse_dw_pw(model)
             for _ in range(2):
                 model(x)
             torch.cuda.synchronize()
@@ -187,6 +189,12 @@ def whole_net(specs, net, batch, dev, steps):
                 model(x)
             torch.cuda.synchronize()
             out[tag] = round(batch * steps / (time.perf_counter() - t0), 1)
+        out["dw_pw_blocks_one_kernel"] = sum(1 for m in model.modules() if isinstance(m, fusion.DwPwBlock) and m._last_kernel)
+        if out["fused_dw_pw"] < out["fused_bn_relu"]:   # replay the faster of the two nets below
+            fusion.unfuse_dw_pw(model)
+            out["hipgraph_net"] = "fused_bn_relu"
+        else:
+            out["hipgraph_net"] = "fused_dw_pw"
         # the fused net replayed as ONE hipGraph (all launches go to the capture stream through the C ABI):
         # removes the per-layer Python/launch latency and the inter-kernel gaps
         try:
@@ -206,14 +214,16 @@ def whole_net(specs, net, batch, dev, steps):
             for _ in range(steps):
                 graph.replay()
             torch.cuda.synchronize()
-            out["fused_bn_relu_hipgraph"] = round(batch * steps / (time.perf_counter() - t0), 1)
+            out["fused_hipgraph"] = round(batch * steps / (time.perf_counter() - t0), 1)
             ref_y = model(static_x)
             out["hipgraph_matches_eager"] = bool(torch.equal(ref_y, static_y))
         except Exception as e:  # graph capture is an optimisation of the secondary number only
-            out["fused_bn_relu_hipgraph"] = None
+            out["fused_hipgraph"] = None
             out["hipgraph_error"] = str(e)[:200]
     out["unit"] = "images/sec"
-    out["note"] = "whole MobileNetV1-224 incl. BN/ReLU/pool/fc through the drop-in modules, 1 GPU, batch %d" % batch
+    out["note"] = ("whole MobileNetV1-224 incl. BN/ReLU/pool/fc through the drop-in modules, 1 GPU, batch %d; fused_dw_pw = "
+                   "fused_bn_relu + the depthwise/pointwise pairs libslfp_hip can run as one kernel (bit-identical; see DESIGN.md for "
+                   "why it is not yet the faster of the two); fused_hipgraph = the faster net replayed as one hipGraph" % batch)
     return out
 
 

@@ -23,7 +23,7 @@ SYMBOLS = (
     "slfp_conv2d_prepare_weights", "slfp_conv2d_prepare_weights_codes", "slfp_conv2d_workspace_bytes", "slfp_conv2d_fwd", "slfp_conv2d_fwd_post",
     "slfp_linear_workspace_bytes", "slfp_linear_fwd", "slfp_linear_prepare_weights", "slfp_linear_fwd_prepared",
     "slfp_nchw_to_nhwc_f32", "slfp_nhwc_to_nchw_f32", "slfp_debug_div_mismatches",
-    "slfp_debug_enc_mismatches", "slfp_enc_table_ok",
+    "slfp_debug_enc_mismatches", "slfp_enc_table_ok", "slfp_dwpw_supported", "slfp_dwpw_fwd",
 )
 
 
@@ -87,6 +87,8 @@ def load():
         "slfp_debug_div_mismatches": (ci, [cf, vp, vp]),
         "slfp_debug_enc_mismatches": (ci, [cf, ci, vp, vp]),
         "slfp_enc_table_ok": (ci, [cf, ci]),
+        "slfp_dwpw_supported": (ci, [dp, dp]),
+        "slfp_dwpw_fwd": (ci, [dp, dp, vp, vp, vp, vp, ci, vp, vp, vp, vp, ci, vp, vp]),
     }
     assert set(sigs) == set(SYMBOLS)
     for name, (res, args) in sigs.items():

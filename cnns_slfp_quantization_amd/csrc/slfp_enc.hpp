@@ -52,6 +52,28 @@ __device__ __forceinline__ void enc_fill(uint2* sTab, const EncArgs& a) {
     for (int i = threadIdx.x; i < kEncEntries; i += NT) sTab[i] = a.e[i];
 }
 
+// Compact form for kernels that need two tables in one 4 KiB kernarg segment: only the 146 entries a clamped
+// quotient can index are live (bins 160..255 = binades 2^-5 .. 2^0, bins 0..49 = binades 2^1 .. 2^3 and their successors).
+constexpr int kEncCompact = 146;
+struct EncArgsCompact {
+    float r1, lo, hi;
+    uint32_t valid;
+    uint2 e[kEncCompact];   // [0, 96): bins 160..255; [96, 146): bins 0..49
+};
+
+inline EncArgsCompact enc_compact(const EncArgs& a) {
+    EncArgsCompact c;
+    c.r1 = a.r1; c.lo = a.lo; c.hi = a.hi; c.valid = a.valid;
+    for (int i = 0; i < kEncCompact; ++i) c.e[i] = a.e[i < 96 ? 160 + i : i - 96];
+    return c;
+}
+
+template <int NT>
+__device__ __forceinline__ void enc_fill_compact(uint2* sTab, const EncArgsCompact& a) {
+    for (int i = threadIdx.x; i < kEncCompact; i += NT) sTab[i < 96 ? 160 + i : i - 96] = a.e[i];
+    if (threadIdx.x == 0) sTab[256] = a.e[96];   // successor of bin 255 = bin 0
+}
+
 // byte offset of the bin of q0c inside the LDS table: bits 19..26 of the pattern, times 8
 __device__ __forceinline__ uint32_t enc_bin_off(float q0c) {
     uint32_t off;

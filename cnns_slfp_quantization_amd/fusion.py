@@ -8,7 +8,15 @@ the BatchNorm2d's running statistics and affine are folded into a per-channel (s
 the HIP epilogue applies after the reference's (out*Ka)*Kw roundings (slfp_conv2d_fwd_post), and
 the BN / ReLU modules are replaced by nn.Identity.  Call it AFTER load_state_dict and model.eval().
 Nets that wire conv->bn by hand (ResNet-50 blocks) can use `fuse_pair(conv, bn, relu)`.
+
+`fuse_dw_pw(model)` goes one step further for MobileNet blocks (second half): an adjacent
+[depthwise Conv2d_Q + BN + ReLU] -> [pointwise Conv2d_Q (+ BN + ReLU)] pair that libslfp_hip can run as ONE kernel
+(slfp_dwpw_fwd: the depthwise result is quantized for the pointwise layer where it is produced and never goes to HBM)
+is replaced by a `DwPwBlock`; the result is bit-identical to the two fused convs run separately.
 """
+import ctypes
+
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -97,5 +105,124 @@ def unfuse(model):
                     seq._modules[key] = mod
                 conv._post = None
                 del conv._fused_modules
+                n += 1
+    return n
+
+
+# ------------------------------------------------------------------ depthwise + pointwise in one kernel
+class DwPwBlock(nn.Module):
+    """[Conv2d_Q 3x3 depthwise, BN, ReLU, Conv2d_Q 1x1, (BN), (ReLU)] as one launch (csrc/conv_dwpw.hip).  Holds the two
+    original conv modules (parameters, state-dict keys and scales unchanged: `dw`, `pw`); inference only.  Falls back
+    to running them one after the other when the input is not a channels_last ROCm tensor of a supported size."""
+
+    def __init__(self, dw, pw):
+        super().__init__()
+        self.dw = dw
+        self.pw = pw
+        self._last_kernel = None
+
+    def forward(self, x):
+        from . import _lib
+        from .conv2d_func import _f32, _scalar_scale, options
+        from .sfp_quant import _stream_handle
+        dw, pw = self.dw, self.pw
+        ok = (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
+              and not self.training and not torch.is_grad_enabled() and options.mfma_passes in (_lib.MFMA_DEFAULT, _lib.MFMA_F16X1)
+              and dw.q_bit in (8, 7) and dw._post is not None and dw._post[0] is not None and not (int(dw._post[2]) & 2)
+              and pw._post is not None and not (int(pw._post[2]) & 2))
+        if not ok:
+            self._last_kernel = None
+            return pw(dw(x))
+        L = _lib.load()
+        N, C, H, W = x.shape
+
+        def desc(m, n, c, h, w):
+            return _lib.ConvDesc(n=n, c_in=c, h=h, w=w, c_out=m.out_channels, kh=m.weight.shape[2], kw=m.weight.shape[3],
+                                 stride_h=m.stride[0], stride_w=m.stride[1], pad_h=m.padding[0], pad_w=m.padding[1], dil_h=1, dil_w=1,
+                                 groups=m.groups, x_layout=_lib.LAYOUT_NHWC, y_layout=_lib.LAYOUT_NHWC, qbits=m.q_bit,
+                                 ka=_f32(_scalar_scale(m.Ka, "Ka")), kw_scale=_f32(_scalar_scale(m.Kw, "Kw")),
+                                 mfma_passes=options.mfma_passes, reserved=0)
+
+        d1 = desc(dw, N, C, H, W)
+        ho, wo = ctypes.c_int64(), ctypes.c_int64()
+        with torch.cuda.device(x.device):
+            _lib.check(L.slfp_conv2d_out_shape(ctypes.byref(d1), ctypes.byref(ho), ctypes.byref(wo)))
+            d2 = desc(pw, N, dw.out_channels, ho.value, wo.value)
+            if not L.slfp_dwpw_supported(ctypes.byref(d1), ctypes.byref(d2)):
+                self._last_kernel = None
+                return pw(dw(x))
+            b1 = dw._prep.get(L, d1, dw.weight, want_weight_q=False, cache=True)
+            b2 = pw._prep.get(L, d2, pw.weight, want_weight_q=False, cache=True)
+            s1, h1, f1 = dw._post
+            s2, h2, f2 = pw._post
+            if s1.device != x.device:
+                s1, h1 = s1.to(x.device), h1.to(x.device)
+                dw._post = (s1, h1, f1)
+            if s2 is not None and s2.device != x.device:
+                s2, h2 = s2.to(x.device), h2.to(x.device)
+                pw._post = (s2, h2, f2)
+            bias2 = pw.bias.detach().contiguous() if (pw.bias is not None and getattr(pw, "_scaled_bias", False)) else None
+            if pw.bias is not None and bias2 is None:
+                return pw(dw(x))   # conv2d_Q's raw bias is added outside the kernels
+            y = torch.empty((N, pw.out_channels, ho.value, wo.value), dtype=torch.float32, device=x.device,
+                            memory_format=torch.channels_last)
+            _lib.check(L.slfp_dwpw_fwd(ctypes.byref(d1), ctypes.byref(d2), x.data_ptr(), b1.data_ptr(), s1.data_ptr(), h1.data_ptr(),
+                                       int(f1) & 1, b2.data_ptr(), bias2.data_ptr() if bias2 is not None else None,
+                                       s2.data_ptr() if s2 is not None else None, h2.data_ptr() if s2 is not None else None,
+                                       int(f2) & 1, y.data_ptr(), _stream_handle(x)))
+        self._last_kernel = "dwpw_fused_f16x1" if dw.q_bit == 8 else "dwpw_fused_f16_exact"
+        dw._last_input, dw._input_q = x.detach(), None
+        pw._last_input, pw._input_q = None, None   # the pointwise input never exists as a tensor
+        return y
+
+
+def _is_dw(m):
+    return _is_conv_q(m) and m.groups == m.in_channels == m.out_channels and tuple(m.kernel_size) == (3, 3)
+
+
+def _is_pw(m):
+    return _is_conv_q(m) and m.groups == 1 and tuple(m.kernel_size) == (1, 1) and tuple(m.stride) == (1, 1)
+
+
+def fuse_dw_pw(model):
+    """After fuse_bn_relu: replace every [depthwise Conv2d_Q (+BN+ReLU folded), Identity..., pointwise Conv2d_Q (+BN+ReLU
+    folded)] run of an nn.Sequential by one DwPwBlock (the pointwise slot; the depthwise slot becomes nn.Identity).
+    Whether a pair really runs as one kernel is decided per call (input layout, size, libslfp_hip's
+    slfp_dwpw_supported); otherwise the block runs its two convs as before.  Returns the number of blocks formed."""
+    n = 0
+    for seq in [m for m in model.modules() if isinstance(m, nn.Sequential)]:
+        names = list(seq._modules.keys())
+        i = 0
+        while i < len(names):
+            dw = seq._modules[names[i]]
+            if _is_dw(dw) and dw._post is not None and dw._post[0] is not None:
+                j = i + 1
+                while j < len(names) and isinstance(seq._modules[names[j]], nn.Identity):
+                    j += 1
+                if j < len(names) and _is_pw(seq._modules[names[j]]) and seq._modules[names[j]]._post is not None \
+                        and seq._modules[names[j]].in_channels == dw.out_channels:
+                    pw = seq._modules[names[j]]
+                    blk = DwPwBlock(dw, pw)
+                    blk.train(dw.training)   # a new module starts in training mode; follow the convs
+                    blk._dw_slot = names[i]
+                    seq._modules[names[j]] = blk
+                    seq._modules[names[i]] = nn.Identity()
+                    n += 1
+                    i = j + 1
+                    continue
+            i += 1
+    return n
+
+
+def unfuse_dw_pw(model):
+    """Undo fuse_dw_pw."""
+    n = 0
+    for seq in [m for m in model.modules() if isinstance(m, nn.Sequential)]:
+        names = list(seq._modules.keys())
+        for j, name in enumerate(names):
+            blk = seq._modules[name]
+            if isinstance(blk, DwPwBlock):
+                seq._modules[blk._dw_slot] = blk.dw
+                seq._modules[name] = blk.pw
                 n += 1
     return n

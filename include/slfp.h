@@ -142,6 +142,21 @@ int slfp_conv2d_fwd_post(const slfp_conv2d_desc* d, const float* x, const void* 
                          const float* post_scale, const float* post_shift, int relu, float* y,
                          float* input_q, void* workspace, void* stream);
 
+/* ---- one MobileNet block in one launch (second half) ---------------------------------------------
+ * nets_imgnet/mobilenetv1.py:24-41's conv_dw block -- Conv2d_Q(3x3, groups = C) -> BatchNorm2d -> ReLU -> Conv2d_Q(1x1)
+ * -> BatchNorm2d -> ReLU -- with the depthwise result quantized for the pointwise layer where it is produced and handed
+ * to the matrix cores through LDS as fp16: the intermediate tensor never goes to HBM.  Bit-identical to
+ * slfp_conv2d_fwd_post(dw) followed by slfp_conv2d_fwd_post(pw) in the single-pass MFMA mode.  `dw` / `pw` are the two
+ * layers' descriptors (NHWC; pw's input size = dw's output size), wprep_* their prepared weights, post1_* the folded
+ * BatchNorm of the depthwise layer (required), post2_* that of the pointwise layer (or NULL), relu*: 0 / 1.
+ * slfp_dwpw_supported: 1 if the pair can be fused (3x3 depthwise stride 1 / 2, C in {32, 64, 128}, N in {64, 128, 256},
+ * C * N * 2 B <= 64 KiB, single-pass mode, threshold tables available for both Ka), else 0. */
+int slfp_dwpw_supported(const slfp_conv2d_desc* dw, const slfp_conv2d_desc* pw);
+int slfp_dwpw_fwd(const slfp_conv2d_desc* dw, const slfp_conv2d_desc* pw, const float* x, const void* wprep_dw,
+                  const float* post1_scale, const float* post1_shift, int relu1, const void* wprep_pw,
+                  const float* bias_pw, const float* post2_scale, const float* post2_shift, int relu2, float* y,
+                  void* stream);
+
 /* ---- linear: replaces Linear_Q.forward (utils/conv2d_func.py:60-65) -------------------
  * out = linear(QA(x/Ka), QW(w/Kw), bias/Kw/Ka) * Kw * Ka   (note the Kw-first order).
  * x: [batch, in_f] row-major, w: [out_f, in_f] row-major, bias: [out_f] or NULL.  The weights

@@ -697,6 +697,52 @@ def test_bias_gradients_of_both_conv_classes(dev):
         assert torch.allclose(m.bias.grad, b.grad, rtol=1e-4, atol=1e-5), (scaled, m.bias.grad, b.grad)
 
 
+def test_fused_depthwise_pointwise_block_is_bit_identical(dev):
+    """SURVEY 8f rank 1, second half (csrc/conv_dwpw.hip): [dw Conv2d_Q, BN, ReLU, pw Conv2d_Q, BN, ReLU] as ONE kernel --
+    the depthwise result is quantized for the pointwise layer where it is produced and never reaches HBM.  Must equal,
+    bit for bit, the two BN-fused convs run one after the other (same quantizer, same FMA order, same MFMA k order);
+    against the stock modules (BatchNorm2d / ReLU as separate ATen ops) the usual 2e-6; and the pointwise layer's
+    would-be input (dw output through the stock modules, quantized) is what the oracle's quantizer gives, bit-exact."""
+    import utils.conv2d_func as cf
+    from cnns_slfp_quantization_amd import fusion
+    g = torch.Generator(device=dev).manual_seed(5)
+    #        C    N   stride  H   batch
+    cases = [(32, 64, 1, 28, 3), (64, 128, 2, 30, 2), (128, 128, 1, 14, 2), (128, 256, 2, 28, 2), (32, 64, 1, 33, 2), (64, 64, 2, 15, 1)]
+    for (C, N, S, H, B) in cases:
+        Ka1, Kw1, Ka2, Kw2 = np.float64(0.21), np.float64(0.11), np.float64(0.33), np.float64(0.07)
+        dw = cf.conv2d_Q(8, Kw1, Ka1)(C, C, 3, Kw1, Ka1, S, 1, groups=C, bias=False)
+        pw = cf.conv2d_Q(8, Kw2, Ka2)(C, N, 1, Kw2, Ka2, 1, 0, bias=False)
+        m = torch.nn.Sequential(dw, torch.nn.BatchNorm2d(C), torch.nn.ReLU(inplace=True), pw, torch.nn.BatchNorm2d(N), torch.nn.ReLU(inplace=True)).to(dev).eval()
+        with torch.no_grad():
+            for bn in (m[1], m[4]):
+                bn.running_mean.normal_(0.0, 0.2, generator=g)
+                bn.running_var.uniform_(0.5, 1.5, generator=g)
+                bn.weight.uniform_(0.8, 1.6, generator=g)
+                bn.bias.normal_(0.1, 0.2, generator=g)
+            dw.weight.mul_(3.0)
+        m = m.to(memory_format=torch.channels_last)
+        x = (torch.randn((B, C, H, H), generator=g, device=dev).abs() * 1.5).contiguous(memory_format=torch.channels_last)
+        with torch.no_grad():
+            y_stock = m(x).clone()
+            mid_stock = m[2](m[1](m[0](x))).clone()
+            assert fusion.fuse_bn_relu(m) == 2
+            y_two = m(x).clone()
+            assert fusion.fuse_dw_pw(m) == 1
+            y_one = m(x).clone()
+            blk = [mod for mod in m if isinstance(mod, fusion.DwPwBlock)][0]
+            assert blk._last_kernel == "dwpw_fused_f16x1", (C, N, S, H, blk._last_kernel)
+        assert torch.equal(y_one, y_two), (C, N, S, H, float((y_one - y_two).abs().max()))
+        e = rel_errors(y_one.cpu().numpy(), y_stock.cpu().numpy())
+        assert max(e) <= 1e-5, (C, N, S, H, e)   # BN folded into one fma vs the stock modules: a few quantizer flips downstream
+        # the quantized intermediate the kernel feeds the MFMA: the oracle's quantizer on the stock-module intermediate
+        q_ref = so.quantize(mid_stock.permute(0, 2, 3, 1).contiguous().cpu().numpy(), np.float32(Ka2), so.FMT_ACT8)
+        with torch.no_grad():
+            assert fusion.unfuse_dw_pw(m) == 1
+            mid_fused = m[2](m[1](m[0](x)))   # BN-fused depthwise alone
+        q_got = so.quantize(mid_fused.permute(0, 2, 3, 1).contiguous().cpu().numpy(), np.float32(Ka2), so.FMT_ACT8)
+        assert np.mean(q_ref.view(np.uint32) != q_got.view(np.uint32)) <= 2e-4   # folded-BN fma vs stock BN: rare one-step flips
+
+
 # ------------------------------------------------------------------ whole net (BASELINE config 1)
 @pytest.mark.parametrize("layout", ["nchw", "channels_last"])
 def test_cifar_mobilenetv1_whole_net(dev, layout):
