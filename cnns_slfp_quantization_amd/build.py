@@ -38,12 +38,13 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     hipcc = _hipcc()
+    extra = os.environ.get("SLFP_EXTRA_HIPCC_FLAGS", "").split()   # experiments only (e.g. -DSLFP_NT=3)
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     procs = []
     for src in SOURCES:
         obj = os.path.join(objdir, src + ".o")
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

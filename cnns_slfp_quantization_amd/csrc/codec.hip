@@ -75,11 +75,12 @@ __global__ __launch_bounds__(kThreads) void k_codec(const float* __restrict__ x,
             r.y = __uint_as_float(quant_bits<FMT>(u1, __float_as_uint(v.y), sT));
             r.z = __uint_as_float(quant_bits<FMT>(u2, __float_as_uint(v.z), sT));
             r.w = __uint_as_float(quant_bits<FMT>(u3, __float_as_uint(v.w), sT));
-            reinterpret_cast<float4*>(out)[i] = r;
+            st_stream4<SLFP_NT_CODEC>(reinterpret_cast<float*>(out) + 4 * i, r);
         } else {
             const uint32_t c = quant_code<FMT>(u0, __float_as_uint(v.x), ext) | (quant_code<FMT>(u1, __float_as_uint(v.y), ext) << 8) |
                                (quant_code<FMT>(u2, __float_as_uint(v.z), ext) << 16) | (quant_code<FMT>(u3, __float_as_uint(v.w), ext) << 24);
-            reinterpret_cast<uint32_t*>(out)[i] = c;
+            if constexpr (SLFP_NT_CODEC & 2) __builtin_nontemporal_store(c, reinterpret_cast<uint32_t*>(out) + i);
+            else reinterpret_cast<uint32_t*>(out)[i] = c;
         }
     }
     // scalar tail (and the whole array when a pointer is not 16-byte aligned)
@@ -107,10 +108,10 @@ __global__ __launch_bounds__(kThreads) void k_quantize_tab(const float* __restri
     const size_t nvec = vec_ok ? n / 4 : 0;
     const size_t stride = (size_t)gridDim.x * kThreads;
     for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += stride) {
-        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        const float4 v = ld_stream4<SLFP_NT_CODEC>(x + 4 * i);
         float4 r = enc4_f32(v, r1, lo, hi, tb);
         r.x += 0.0f; r.y += 0.0f; r.z += 0.0f; r.w += 0.0f;
-        reinterpret_cast<float4*>(y)[i] = r;
+        st_stream4<SLFP_NT_CODEC>(y + 4 * i, r);
     }
     for (size_t i = nvec * 4 + (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
         const float xi = x[i];

@@ -94,8 +94,8 @@ __global__ __launch_bounds__(256) void k_dense_encode(const float* __restrict__ 
     const int c0 = (cj >> 2) * 32 + (cj & 3) * 4;
     const float* xp = x + pix * C;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-    if (c0 < C) a = *reinterpret_cast<const float4*>(xp + c0);
-    if (c0 + 16 < C) b = *reinterpret_cast<const float4*>(xp + c0 + 16);
+    if (c0 < C) a = ld_stream4<SLFP_NT_DENSE>(xp + c0);
+    if (c0 + 16 < C) b = ld_stream4<SLFP_NT_DENSE>(xp + c0 + 16);
     float v[8] = {quantize_scaled<FMT, 4>(a.x, sd, sT), quantize_scaled<FMT, 4>(a.y, sd, sT),
                   quantize_scaled<FMT, 4>(a.z, sd, sT), quantize_scaled<FMT, 4>(a.w, sd, sT),
                   quantize_scaled<FMT, 4>(b.x, sd, sT), quantize_scaled<FMT, 4>(b.y, sd, sT),
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(kDnThreads, (MT == 4 || PASSES == 3 ? 2 : 4)) void 
             r.y = ((acc[i][j][1] + bq.y) * p.s1x) * p.s2;
             r.z = ((acc[i][j][2] + bq.z) * p.s1x) * p.s2;
             r.w = ((acc[i][j][3] + bq.w) * p.s1x) * p.s2;
-            *reinterpret_cast<float4*>(p.y + (((size_t)n * p.Ho + goh) * p.Wo + gow) * p.O + ch) = post_apply_v(r, p.post, pv);
+            st_stream4<SLFP_NT_DENSE>(p.y + (((size_t)n * p.Ho + goh) * p.Wo + gow) * p.O + ch, post_apply_v(r, p.post, pv));
         }
     }
 }

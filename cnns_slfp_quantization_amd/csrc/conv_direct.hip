@@ -380,7 +380,7 @@ __global__ __launch_bounds__(256) void k_stem_fixed(const float* __restrict__ x,
                 r.y = ((acc[q].y + bq.y) * p.s1) * p.s2;
                 r.z = ((acc[q].z + bq.z) * p.s1) * p.s2;
                 r.w = ((acc[q].w + bq.w) * p.s1) * p.s2;
-                *reinterpret_cast<float4*>(yb + (uint32_t)(q * p.Wo * O)) = post_apply_v(r, p.post, pv);
+                st_stream4<SLFP_NT_STEM>(yb + (uint32_t)(q * p.Wo * O), post_apply_v(r, p.post, pv));
             }
         }
         return;
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256) void k_stem_fixed(const float* __restrict__ x,
             r.y = ((acc[q].y + bq.y) * p.s1) * p.s2;
             r.z = ((acc[q].z + bq.z) * p.s1) * p.s2;
             r.w = ((acc[q].w + bq.w) * p.s1) * p.s2;
-            *reinterpret_cast<float4*>(yb + (uint32_t)(q * p.Wo * O)) = post_apply(r, p.post, c4 * 4);
+            st_stream4<SLFP_NT_STEM>(yb + (uint32_t)(q * p.Wo * O), post_apply(r, p.post, c4 * 4));
         }
     }
 }

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(kDw2Threads, 4) void k_dw3x3_tile(const float* __re
         }
 #pragma unroll
         for (int i = 0; i < NI; ++i)
-            v[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[i], 0, 0));
+            v[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[i], 0, (SLFP_NT_DW & 1) ? 2 : 0));
     }
     __syncthreads();   // threshold table visible
 
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(kDw2Threads, 4) void k_dw3x3_tile(const float* __re
         const bool live = ocol_live && (oh0 + ohb + j * RPI) < p.Ho && (j * RPI + ohb) < TH && (ow0 + ow) < p.Wo;
         uint32_t so = live ? org + out_rel0 + (uint32_t)j * out_step : kOob;
         asm volatile("" : "+v"(so));
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned int, rr), ry, so, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned int, rr), ry, so, 0, (SLFP_NT_DW & 2) ? 2 : 0);
     }
 }
 

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(kStreamThreads) void k_pw_stream(const PwParams p) 
                         if (k + 2 >= p.K) b = make_float2(0.f, 0.f);
                         raw[c][hf] = make_float4(a.x, a.y, b.x, b.y);
                     } else if constexpr (KFULL) {
-                        raw[c][hf] = *reinterpret_cast<const float4*>(xr + (c0 + c) * 32 + hf * 16);
+                        raw[c][hf] = ld_stream4<SLFP_NT_PW>(xr + (c0 + c) * 32 + hf * 16);
                     } else {
                         const int k = (c0 + c) * 32 + hf * 16 + kq * 4;
                         raw[c][hf] = *reinterpret_cast<const float4*>(xr + (k < p.K ? (c0 + c) * 32 + hf * 16 : p.K - 4 - kq * 4));
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(kStreamThreads) void k_pw_stream(const PwParams p) 
                     const u32x4 v = *reinterpret_cast<const u32x4*>(stg + lane * 16 + h * 1024);
                     uint32_t so = ch_ok ? (uint32_t)((spx + 8 * h) * p.N + j0 * 16 + sch * 4) * 4u : 0xFFFFFFF0u;
                     asm volatile("" : "+v"(so));
-                    __builtin_amdgcn_raw_buffer_store_b128(v, ry, so, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(v, ry, so, 0, (SLFP_NT_PW_STG & 2) ? 2 : 0);
                 }
             }
         } else {
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(kStreamThreads) void k_pw_stream(const PwParams p) 
                     if (live && n < p.N) *reinterpret_cast<float2*>(yr + j * 16) = make_float2(r.x, r.y);
                     if (live && n + 2 < p.N) *reinterpret_cast<float2*>(yr + j * 16 + 2) = make_float2(r.z, r.w);
                 } else {
-                    if (live && n < p.N) *reinterpret_cast<float4*>(yr + j * 16) = r;
+                    if (live && n < p.N) st_stream4<SLFP_NT_PW>(yr + j * 16, r);
                 }
             }
         }
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 4) void k_pw_til
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             if constexpr (KFULL) {
-                st[i] = *reinterpret_cast<const float4*>(src[i] + t * 64);
+                st[i] = ld_stream4<SLFP_NT_PW>(src[i] + t * 64);
             } else {
                 const int k = t * 64 + kc * 4;
                 const int kk = k < p.K ? t * 64 : p.K - 4 - kc * 4;  // clamp inside the row
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 4) void k_pw_til
                 if (p.post.layerout) r = layerout4(r);
             }
             if (p.post.relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
-            *reinterpret_cast<float4*>(p.y + (size_t)m * p.N + n) = r;
+            st_stream4<SLFP_NT_PW>(p.y + (size_t)m * p.N + n, r);
         }
     }
 }

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(kSsThreads) void k_stem_small(const StemSmallParams
                 r.y = ((acc[j][1] + bq.y) * p.s1x) * p.s2;
                 r.z = ((acc[j][2] + bq.z) * p.s1x) * p.s2;
                 r.w = ((acc[j][3] + bq.w) * p.s1x) * p.s2;
-                *reinterpret_cast<float4*>(yp + ch) = post_apply_v(r, p.post, pvv[j]);
+                st_stream4<SLFP_NT_STEM_MFMA>(yp + ch, post_apply_v(r, p.post, pvv[j]));
             }
         }
     }

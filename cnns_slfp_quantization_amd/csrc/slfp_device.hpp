@@ -20,6 +20,53 @@
 
 namespace slfp {
 
+// Cache policy of the once-through activation streams, per kernel family (bit 0: loads, bit 1: stores carry the
+// `nt` hint).  Measured in the bench's cold order (profiles/ab_nt.sh, ab_nt2.sh; MobileNetV1-224, batch 256):
+// depthwise 1.096 -> 1.00 ms per step with nt stores (nt loads as well: the depthwise kernels gain another 3 % but the
+// pointwise kernels that run after them lose 4 %, profiles/ab_flags.sh), stem 0.133 -> 0.121; pointwise: the hint pays only where a wave
+// stores whole 128-byte lines (the staged stores of k_pw_stream: 240 -> 219 us on 32->64 @112) and costs 5-25 % on the
+// 64-byte-piece stores and on the loads; slfp_quantize_f32 4.93 -> 5.59 TB/s with nt stores; dense (VGG-16): no effect.
+#ifndef SLFP_NT_DW
+#define SLFP_NT_DW 2
+#endif
+#ifndef SLFP_NT_STEM
+#define SLFP_NT_STEM 3
+#endif
+#ifndef SLFP_NT_PW
+#define SLFP_NT_PW 0
+#endif
+#ifndef SLFP_NT_PW_STG
+#define SLFP_NT_PW_STG 2
+#endif
+#ifndef SLFP_NT_STEM_MFMA
+#define SLFP_NT_STEM_MFMA 0
+#endif
+#ifndef SLFP_NT_CODEC
+#define SLFP_NT_CODEC 2
+#endif
+#ifndef SLFP_NT_DENSE
+#define SLFP_NT_DENSE 0
+#endif
+typedef float nt_f32x4 __attribute__((ext_vector_type(4)));
+template <int POLICY>
+__device__ __forceinline__ float4 ld_stream4(const float* p) {
+    if constexpr (POLICY & 1) {
+        const nt_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f32x4*>(p));
+        return make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+        return *reinterpret_cast<const float4*>(p);
+    }
+}
+template <int POLICY>
+__device__ __forceinline__ void st_stream4(float* p, const float4 r) {
+    if constexpr (POLICY & 2) {
+        __builtin_nontemporal_store(nt_f32x4{r.x, r.y, r.z, r.w}, reinterpret_cast<nt_f32x4*>(p));
+    } else {
+        *reinterpret_cast<float4*>(p) = r;
+    }
+}
+
+
 constexpr int kFmtAct8 = 0;  // quantize_act(8)     utils/sfp_quant.py:80-96
 constexpr int kFmtW8 = 1;    // quantize_weight(8)  utils/sfp_quant.py:32-47
 constexpr int kFmtSfp7 = 2;  // quantize_*(7)       utils/sfp_quant.py:14-30, 63-78
