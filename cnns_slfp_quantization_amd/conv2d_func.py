@@ -31,6 +31,7 @@ There is no CPU compute path here (q_bit 8/7 need a ROCm tensor; q_bit 32 is the
 reference's passthrough).  Autograd: forward is always the HIP kernel; backward is the
 reference's STE composite on the GPU (training is outside the accelerated scope).
 """
+import contextlib
 import ctypes
 
 import numpy as np
@@ -52,6 +53,7 @@ class _Options:
     mfma_passes = _lib.MFMA_DEFAULT  # pointwise MFMA operand precision, see include/slfp.h
     output_layout = "same"           # "same": follow the input's memory format; "nhwc": always channels_last
     eager_stash = False              # True: materialise input_q / weight_q on every forward like the reference
+    plan_cache = True                # False: rebuild descriptor / shapes / workspace on every call (host-overhead A/B)
 
 
 options = _Options()
@@ -72,6 +74,15 @@ def _scalar_scale(t, name):
     return v
 
 
+def _scale_key(t, name):
+    """The scale as a Python float for the plan key (validated like _scalar_scale, without its tensor round trip)."""
+    if torch.is_tensor(t):
+        if t.numel() != 1:
+            _scalar_scale(t, name)
+        return t.item()
+    return float(t)
+
+
 def _pair(v):
     return (int(v[0]), int(v[1])) if isinstance(v, (tuple, list)) else (int(v), int(v))
 
@@ -89,9 +100,9 @@ class _PreparedWeights:
         self.blob = None
         self.weight_q = None
 
-    def get(self, L, desc, weight, want_weight_q, cache=True):
+    def get(self, L, desc, weight, want_weight_q, cache=True, kernel=None):
         key = (weight.device, weight.data_ptr(), weight._version, tuple(weight.shape), desc.qbits,
-               desc.kw_scale, L.slfp_conv2d_kernel_name(ctypes.byref(desc)))
+               desc.kw_scale, kernel if kernel is not None else L.slfp_conv2d_kernel_name(ctypes.byref(desc)))
         if not cache or key != self.key or self.blob is None or (want_weight_q and self.weight_q is None):
             nbytes = L.slfp_conv2d_wprep_bytes(ctypes.byref(desc))
             w = weight.detach()
@@ -103,6 +114,38 @@ class _PreparedWeights:
                                                      _stream_handle(weight)))
             self.key, self.blob, self.weight_q = key, blob, wq
         return self.blob
+
+
+class _Plan:
+    """What one (module, input shape, layout, scales, precision) combination resolves to in the C ABI."""
+    __slots__ = ("desc", "ho", "wo", "ws_bytes", "kernel")
+
+    def __init__(self, desc, ho, wo, ws_bytes, kernel):
+        self.desc, self.ho, self.wo, self.ws_bytes, self.kernel = desc, ho, wo, ws_bytes, kernel
+
+
+_workspaces = {}
+_same_device = contextlib.nullcontext()
+
+
+def _on_device(device):
+    """torch.cuda.device(device) only when it is not the current one already (the guard costs ~5 us per call)."""
+    return _same_device if device.index == torch.cuda.current_device() else torch.cuda.device(device)
+
+
+def _workspace(device, nbytes):
+    """Scratch for the kernels that need one (the dense path's pre-encoded input), reused across calls: one buffer per
+    (device, stream), grown to the largest request.  Calls on one stream are ordered, so consecutive layers can share
+    it; a different stream gets its own.  Under hipGraph capture a fresh tensor is taken from the graph's pool instead
+    (the captured pointer must stay valid for the graph's lifetime)."""
+    if torch.cuda.is_current_stream_capturing() or not options.plan_cache:
+        return torch.empty(nbytes, dtype=torch.uint8, device=device)
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf
 
 
 def _hip_conv2d(mod, x, weight, bias, cache_ok=False):
@@ -126,25 +169,36 @@ def _hip_conv2d(mod, x, weight, bias, cache_ok=False):
     if C != mod.in_channels:
         raise RuntimeError(f"Given groups={mod.groups}, weight of size {list(weight.shape)}, expected input"
                            f"{list(x.shape)} to have {mod.in_channels} channels, but got {C} channels instead")
-    sh, sw = _pair(mod.stride)
-    ph, pw = _pair(mod.padding)
-    dh, dw = _pair(mod.dilation)
     nhwc_out = nhwc_in or options.output_layout == "nhwc"
-    d = _lib.ConvDesc(n=N, c_in=C, h=H, w=W, c_out=mod.out_channels, kh=weight.shape[2], kw=weight.shape[3],
-                      stride_h=sh, stride_w=sw, pad_h=ph, pad_w=pw, dil_h=dh, dil_w=dw, groups=mod.groups,
-                      x_layout=_lib.LAYOUT_NHWC if nhwc_in else _lib.LAYOUT_NCHW,
-                      y_layout=_lib.LAYOUT_NHWC if nhwc_out else _lib.LAYOUT_NCHW,
-                      qbits=mod.q_bit, ka=_f32(_scalar_scale(mod.Ka, "Ka")), kw_scale=_f32(_scalar_scale(mod.Kw, "Kw")),
-                      mfma_passes=options.mfma_passes, reserved=0)
-    ho, wo = ctypes.c_int64(), ctypes.c_int64()
-    with torch.cuda.device(x.device):
+    # Everything that depends only on (module geometry, input shape, layouts, scales, precision) is computed once
+    # per distinct key and kept on the module: descriptor, output shape, workspace size, kernel name.
+    ka, kw_ = _scale_key(mod.Ka, "Ka"), _scale_key(mod.Kw, "Kw")
+    pkey = (N, H, W, nhwc_in, nhwc_out, ka, kw_, options.mfma_passes, mod.stride, mod.padding, mod.dilation, tuple(weight.shape))
+    plan = mod._plans.get(pkey) if options.plan_cache else None
+    if plan is None:
+        sh, sw = _pair(mod.stride)
+        ph, pw = _pair(mod.padding)
+        dh, dw = _pair(mod.dilation)
+        d = _lib.ConvDesc(n=N, c_in=C, h=H, w=W, c_out=mod.out_channels, kh=weight.shape[2], kw=weight.shape[3],
+                          stride_h=sh, stride_w=sw, pad_h=ph, pad_w=pw, dil_h=dh, dil_w=dw, groups=mod.groups,
+                          x_layout=_lib.LAYOUT_NHWC if nhwc_in else _lib.LAYOUT_NCHW,
+                          y_layout=_lib.LAYOUT_NHWC if nhwc_out else _lib.LAYOUT_NCHW,
+                          qbits=mod.q_bit, ka=_f32(_scalar_scale(mod.Ka, "Ka")), kw_scale=_f32(_scalar_scale(mod.Kw, "Kw")),
+                          mfma_passes=options.mfma_passes, reserved=0)
+        ho, wo = ctypes.c_int64(), ctypes.c_int64()
         _lib.check(L.slfp_conv2d_out_shape(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)))
+        plan = _Plan(d, ho.value, wo.value, L.slfp_conv2d_workspace_bytes(ctypes.byref(d)),
+                     L.slfp_conv2d_kernel_name(ctypes.byref(d)).decode())
+        if len(mod._plans) >= 64:   # a net fed ever-changing shapes: do not grow without bound
+            mod._plans.clear()
+        mod._plans[pkey] = plan
+    d = plan.desc
+    with _on_device(x.device):
         # cache the prepared weights only where they cannot change unseen: inference (see the module docstring)
-        blob = mod._prep.get(L, d, weight, want_weight_q=options.eager_stash, cache=cache_ok)
-        y = torch.empty((N, mod.out_channels, ho.value, wo.value), dtype=torch.float32, device=x.device,
+        blob = mod._prep.get(L, d, weight, want_weight_q=options.eager_stash, cache=cache_ok, kernel=plan.kernel)
+        y = torch.empty((N, mod.out_channels, plan.ho, plan.wo), dtype=torch.float32, device=x.device,
                         memory_format=torch.channels_last if nhwc_out else torch.contiguous_format)
-        ws_bytes = L.slfp_conv2d_workspace_bytes(ctypes.byref(d))
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None
+        ws = _workspace(x.device, plan.ws_bytes) if plan.ws_bytes else None
         b = None
         if bias is not None:
             b = bias.detach()
@@ -164,7 +218,7 @@ def _hip_conv2d(mod, x, weight, bias, cache_ok=False):
                                           psh.data_ptr() if psh is not None else None, int(relu), y.data_ptr(),
                                           xq.data_ptr() if xq is not None else None,
                                           ws.data_ptr() if ws is not None else None, _stream_handle(x)))
-    mod._last_kernel = L.slfp_conv2d_kernel_name(ctypes.byref(d)).decode()
+    mod._last_kernel = plan.kernel
     mod._last_input = x.detach()
     mod._input_q = xq
     return y.squeeze(0) if squeeze else y
@@ -226,6 +280,7 @@ def _conv_class(q_bit, Kw, Ka, bias_default, scaled_bias):
             self.Kw = torch.tensor(Kw)
             self.Ka = torch.tensor(Ka)
             self._prep = _PreparedWeights()
+            self._plans = {}
             self._last_input = None
             self._input_q = None
             self._weight_q32 = None

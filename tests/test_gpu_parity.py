@@ -676,6 +676,50 @@ def test_weights_updated_through_data_are_requantized(dev):
     assert not torch.allclose(a, lin(xl).detach())
 
 
+def test_plan_cache_follows_scales_shapes_and_layouts(dev):
+    """The per-module plan cache (descriptor, output shape, workspace size, kernel name per input shape / layout /
+    scales / precision) must never serve a stale plan: new Ka / Kw, a new input shape or layout, and a new precision
+    each give what a freshly built module gives, and the dense path's reused workspace does not leak between layers."""
+    import utils.conv2d_func as cf
+    from cnns_slfp_quantization_amd.conv2d_func import options
+    Ka, Kw = np.float64(0.17), np.float64(0.12)
+    m = cf.conv2d_Q(8, Kw, Ka)(32, 64, 3, Kw, Ka, 1, 1).to(dev).eval()
+    m2 = cf.conv2d_Q(8, Kw, Ka)(64, 32, 3, Kw, Ka, 2, 1).to(dev).eval()      # second dense layer sharing the workspace
+    xs = [torch.relu(torch.randn(2, 32, 14, 14, device=dev)), torch.relu(torch.randn(3, 32, 9, 11, device=dev)),
+          torch.relu(torch.randn(2, 32, 14, 14, device=dev)).contiguous(memory_format=torch.channels_last)]
+
+    def fresh(x, ka, kw, passes):
+        f = cf.conv2d_Q(8, kw, ka)(32, 64, 3, kw, ka, 1, 1).to(dev).eval()
+        f.load_state_dict(m.state_dict())
+        old, options.plan_cache, options.mfma_passes = (options.plan_cache, options.mfma_passes), False, passes
+        try:
+            return f(x)
+        finally:
+            options.plan_cache, options.mfma_passes = old
+
+    with torch.no_grad():
+        for x in xs + xs:
+            assert torch.equal(m(x), fresh(x, Ka, Kw, options.mfma_passes))
+            y2 = m2(m(x))                                   # workspace reused by the next layer on the stream
+            assert torch.equal(m(x), fresh(x, Ka, Kw, options.mfma_passes))
+            assert torch.isfinite(y2).all()
+        n_plans = len(m._plans)
+        assert n_plans == 3
+        m.Ka = torch.tensor(np.float64(0.31))
+        m.Kw = torch.tensor(np.float64(0.05))
+        assert torch.equal(m(xs[0]), fresh(xs[0], np.float64(0.31), np.float64(0.05), options.mfma_passes))
+        assert len(m._plans) == n_plans + 1
+        old = options.mfma_passes
+        try:
+            options.mfma_passes = 3
+            assert torch.equal(m(xs[0]), fresh(xs[0], np.float64(0.31), np.float64(0.05), 3))
+        finally:
+            options.mfma_passes = old
+        m.Ka = torch.tensor([0.1, 0.2])
+        with pytest.raises(ValueError):
+            m(xs[0])
+
+
 def test_bias_gradients_of_both_conv_classes(dev):
     """conv2d_Q hands the raw bias to F.conv2d (utils/conv2d_func.py:23), conv2d_Q_bias divides it by Ka and Kw first
     (:44): in both cases d(out)/d(bias) must be what autograd gives the reference composite (round 1 double-counted the
