@@ -327,9 +327,13 @@ __device__ __forceinline__ uint32_t lds_x_off(int row, int chunk16) {
 // output tiles are clamped and never stored) and the loop body has no branches: with a
 // per-load `if` hipcc cannot count the loads in flight and falls back to s_waitcnt vmcnt(0)
 // in the middle of the MFMA block, draining the HBM loads it has just issued (r01c ISA).
-template <int FMT, int PASSES, int WM, int WN, int MT, int NT, bool KFULL, bool TAB = false>
+// STG: the epilogue goes through a per-wave LDS staging area so that every store instruction writes whole 256-byte runs
+// (4 pixel rows x the wave's 64 adjacent channels) instead of 64-byte pieces, with the nt hint (SLFP_NT_PW_STG).
+constexpr int kStgRow = 272;   // 256 B of a row's 64 channels + 16: the 16 rows' float4 writes spread over the banks
+template <int FMT, int PASSES, int WM, int WN, int MT, int NT, bool KFULL, bool TAB = false, bool STG = false>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 4) void k_pw_tiled(const PwParams p) {
     static_assert(!TAB || PASSES == 1, "the table form produces the single fp16 operand");
+    static_assert(!STG || NT == 4, "the staged epilogue stores a wave's 64 channels per row");
     constexpr int TABB = TAB ? kPwTab : 64;
     constexpr int T = 64 * WM * WN;
     constexpr int BM = WM * MT * 16;
@@ -480,6 +484,44 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 4) void k_pw_til
         }
         __syncthreads();
     }
+    if constexpr (STG) {
+        unsigned char* stg = xs + 2 * (PASSES == 3 ? 2 : 1) * XBYTES + wave * (16 * kStgRow);   // private to this wave
+        const uint64_t left = (uint64_t)(p.M - m0) * p.N * 4;
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y + (size_t)m0 * p.N, 0,
+                                                                             (uint32_t)(left > 0xFFFFFFFFull ? 0xFFFFFFFFull : left), 0x00020000);
+        const int srow = lane >> 4, sch = lane & 15;
+        const int n_st = ntile0 * 16 + sch * 4;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int n = (ntile0 + j) * 16 + kq * 4;
+                const bool in = n < p.N;   // channel tiles past C_out: computed from clamped weights, never stored
+                float4 r = epilogue(acc[i][j], in ? bias_q256(p, n) : make_float4(0.f, 0.f, 0.f, 0.f), p.s1x, p.s2);
+                if (p.post.scale) {
+                    const float4 sc = *reinterpret_cast<const float4*>(lsc + (in ? n - n_lo : 0));
+                    const float4 sh = *reinterpret_cast<const float4*>(lsh + (in ? n - n_lo : 0));
+                    r.x = __builtin_fmaf(r.x, sc.x, sh.x); r.y = __builtin_fmaf(r.y, sc.y, sh.y);
+                    r.z = __builtin_fmaf(r.z, sc.z, sh.z); r.w = __builtin_fmaf(r.w, sc.w, sh.w);
+                    if (p.post.layerout) r = layerout4(r);
+                }
+                if (p.post.relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+                *reinterpret_cast<float4*>(stg + col * kStgRow + j * 64 + kq * 16) = r;
+            }
+            // LDS operations of one wave execute in order: the reads see the writes, the next tile's writes follow the reads
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                const int row = (wm * MT + i) * 16 + h * 4 + srow;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(stg + (h * 4 + srow) * kStgRow + sch * 16);
+                const bool ok = row < p.rb && m0 + row < p.M && n_st < p.N;
+                uint32_t so = ok ? (uint32_t)(row * p.N + n_st) * 4u : 0xFFFFFFF0u;
+                asm volatile("" : "+v"(so));
+                __builtin_amdgcn_raw_buffer_store_b128(v, ry, so, 0, (SLFP_NT_PW_STG & 2) ? 2 : 0);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int n = (ntile0 + j) * 16 + kq * 4;
@@ -523,6 +565,16 @@ static int launch_tiled_k(PwParams& p, hipStream_t stream) {
     p.nblocks = (uint32_t)nblocks;
     if constexpr (PASSES == 1) {
         if (p.enc.valid) {
+            if constexpr (NT == 4) {
+                if (!getenv("SLFP_PW_NOSTG")) {   // per-call A/B switch (profiles/variants.py)
+                    const size_t lds = kPwTab + (size_t)2 * BM * 128 + (size_t)(T / 64) * 16 * kStgRow;
+                    auto fn = k_pw_tiled<FMT, 1, WM, WN, MT, NT, KFULL, true, true>;
+                    int rc = set_lds_limit(reinterpret_cast<const void*>(fn), lds);
+                    if (rc != SLFP_OK) return rc;
+                    hipLaunchKernelGGL(fn, dim3(p.nblocks), dim3(T), lds, stream, p);
+                    return check_launch("slfp pointwise (tiled) kernel");
+                }
+            }
             const size_t lds = kPwTab + (size_t)2 * BM * 128;
             auto fn = k_pw_tiled<FMT, 1, WM, WN, MT, NT, KFULL, true>;
             int rc = set_lds_limit(reinterpret_cast<const void*>(fn), lds);
@@ -549,9 +601,12 @@ template <int FMT, int PASSES, int KS>
 static int launch_stream_ks(PwParams& p, hipStream_t stream) {
     bool tab = false;
     if constexpr (PASSES == 1) tab = p.enc.valid != 0;
-    // staged 128-byte stores pay where stores dominate and follow each other closely (K <= 64: pw1 -14 %, pw2 -13 %);
-    // neutral at K = 128, a loss at K = 256 (same-box A/B, profiles/variants.py)
-    const bool stg = tab && KS <= 2 && !(p.K % 4 || p.N % 4) && !getenv("SLFP_PW_NOSTG");
+    // staged 128-byte stores (with the nt hint) pay where stores dominate and follow each other closely (K <= 64: pw1
+    // -14 %, pw2 -13 %) and at K = 256 (256->256 @28: 113 -> 97-105 us); at K = 128 they lose 5-8 % (same-box A/B,
+    // profiles/variants.py --var SLFP_PW_STG_MAXKS=4 / 8)
+    const char* mk = getenv("SLFP_PW_STG_MAXKS");   // experiment switch
+    const bool stg_ks = mk ? KS <= atoi(mk) : (KS <= 2 || KS == 8);
+    const bool stg = tab && stg_ks && !(p.K % 4 || p.N % 4) && !getenv("SLFP_PW_NOSTG");
     const size_t lds = (tab ? kPwTab : 64) + (size_t)(PASSES == 3 ? 2 : 1) * p.n_tiles * p.KS * 1024 + (size_t)3 * p.n_tiles * 16 * sizeof(float) +
                        (stg ? (size_t)(kStreamThreads / 64) * 2048 : 0);
     auto fn = (p.K % 4 || p.N % 4) ? k_pw_stream<FMT, PASSES, KS, false, true>
