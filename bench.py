@@ -220,6 +220,26 @@ def whole_net(specs, net, batch, dev, steps):
         except Exception as e:  # graph capture is an optimisation of the secondary number only
             out["fused_hipgraph"] = None
             out["hipgraph_error"] = str(e)[:200]
+    # small batch: host- and launch-bound eager vs graph.GraphedModule (one hipGraph per input signature)
+    try:
+        from cnns_slfp_quantization_amd.graph import GraphedModule
+        xs = x[:8].contiguous(memory_format=torch.channels_last)
+        fast = GraphedModule(model)
+        small = {}
+        with torch.no_grad():
+            for tag, fn in (("eager", model), ("hipgraph", fast)):
+                for _ in range(3):
+                    fn(xs)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(50):
+                    fn(xs)
+                torch.cuda.synchronize()
+                small[tag] = round(8 * 50 / (time.perf_counter() - t0), 1)
+            small["hipgraph_matches_eager"] = bool(torch.equal(fast(xs), model(xs)))
+        out["batch8"] = small
+    except Exception as e:  # secondary number only
+        out["batch8"] = {"error": str(e)[:200]}
     out["unit"] = "images/sec"
     out["note"] = ("whole MobileNetV1-224 incl. BN/ReLU/pool/fc through the drop-in modules, 1 GPU, batch %d; fused_dw_pw = "
                    "fused_bn_relu + the depthwise/pointwise pairs libslfp_hip can run as one kernel (bit-identical; see DESIGN.md for "

@@ -62,10 +62,11 @@ def _is_layerout(m):
     return type(m).__name__ == "layerout_quantize_func" and getattr(m, "q_bit", 32) in (8, 7)
 
 
-def fuse_bn_relu(model):
+def fuse_bn_relu(model, dw_pw=False):
     """Fuse every [Conv2d_Q, BatchNorm2d(eval), (layerout_quantize_func), (ReLU)] run found in nn.Sequential
     containers (nets_imgnet/mobilenetv1.py:24-41; nets_cifar/mobilenetv1.py:196-231 for the layerout form; a
-    Swish / GELU after the quantizer stays a module).  Returns the number of fused convolutions."""
+    Swish / GELU after the quantizer stays a module).  Returns the number of fused convolutions.
+    dw_pw=True additionally pairs depthwise and pointwise convs into one kernel where supported (fuse_dw_pw)."""
     n = 0
     for seq in [m for m in model.modules() if isinstance(m, nn.Sequential)]:
         names = list(seq._modules.keys())
@@ -90,11 +91,14 @@ def fuse_bn_relu(model):
                     i = j
                     continue
             i += 1
+    if dw_pw:
+        fuse_dw_pw(model)
     return n
 
 
 def unfuse(model):
-    """Undo fuse_bn_relu (restores the original BatchNorm2d / ReLU modules)."""
+    """Undo fuse_bn_relu (restores the original BatchNorm2d / ReLU modules; un-pairs DwPwBlocks first)."""
+    unfuse_dw_pw(model)
     n = 0
     for seq in [m for m in model.modules() if isinstance(m, nn.Sequential)]:
         names = list(seq._modules.keys())

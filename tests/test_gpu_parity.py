@@ -831,6 +831,47 @@ def test_cifar_mobilenetv1_whole_net(dev, layout):
         cf.options.mfma_passes = 0
 
 
+def test_cifar_mobilenetv1_fused_paths_and_hipgraph(dev):
+    """BASELINE config 1 through the inference-time rewrites: fuse_bn_relu (BN/ReLU in the conv epilogues), the
+    depthwise+pointwise pairs as one kernel where the library supports them (fuse_bn_relu(dw_pw=True)), and the whole
+    forward replayed as one hipGraph (graph.GraphedModule).  Each must stay inside the golden's whole-net bar; pairing
+    and graph replay must not change a single bit; unfuse() must restore the original modules."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import netgen
+    import utils.conv2d_func as cf
+    from cnns_slfp_quantization_amd import fusion, layer_specs
+    from cnns_slfp_quantization_amd.graph import GraphedModule
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "net_golden.npz"))
+    rows = layer_specs.nets()["mobilenetv1_cifar32"]["layers"]
+    scales = [(r["Ka"], r["Kw"]) for r in rows]
+    x = netgen.net_input().to(dev).contiguous(memory_format=torch.channels_last)
+    m = netgen.fill_parameters(netgen.build_mobilenetv1_cifar(cf.conv2d_Q, cf.linear_Q, 8, scales)).to(dev).eval()
+    m = m.to(memory_format=torch.channels_last)
+    with torch.no_grad():
+        y_eager = m(x).clone()
+        n_fused = fusion.fuse_bn_relu(m)
+        assert n_fused >= 27
+        y_bn = m(x).clone()
+        n_pairs = fusion.fuse_dw_pw(m)
+        y_pair = m(x).clone()
+        one_kernel = [b for b in m.modules() if isinstance(b, fusion.DwPwBlock) and b._last_kernel == "dwpw_fused_f16x1"]
+        assert n_pairs == 13 and len(one_kernel) >= 1, (n_pairs, len(one_kernel))
+        assert torch.equal(y_pair, y_bn)
+        fast = GraphedModule(m)
+        for xi in (x, torch.flip(x, dims=[0]), x[:3].contiguous(memory_format=torch.channels_last)):
+            assert torch.equal(fast(xi), m(xi))
+            assert torch.equal(fast(xi), m(xi))     # replay
+        assert len(fast._entries) == 2
+        assert fusion.unfuse(m) == n_fused
+        assert not any(isinstance(b, fusion.DwPwBlock) for b in m.modules())
+        assert torch.equal(m(x), y_eager)
+    for y in (y_eager, y_bn):
+        e = rel_errors(y.cpu().numpy(), gold["logits_q8"])
+        assert max(e) <= 5e-2, e
+    assert (y_bn.argmax(1).cpu().numpy() == gold["logits_q8"].argmax(1)).mean() >= 0.75
+
+
 def test_config2_mobilenetv1_224_whole_net_golden(dev):
     """BASELINE config 2 end to end: tests/golden/net224_golden.npz holds the logits of the REFERENCE
     nets_imgnet/mobilenetv1.py (Qbits 8, 224x224) for 64 seeded images, with deterministic weights and BatchNorm
