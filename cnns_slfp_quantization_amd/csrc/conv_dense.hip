@@ -36,6 +36,7 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 constexpr int kDnThreads = 512;
 constexpr int kDnTW = 16;  // output columns per tile = one MFMA pixel tile
+constexpr int kMaxSlots = 9;   // halo pieces a wave stages per chunk = ceil(x_pieces / 8); dense_cfg_geometry enforces it
 
 struct DenseParams {
     const _Float16* xe;  // pre-encoded input, NHWC with C padded to Cp (k_dense_encode)
@@ -115,7 +116,8 @@ __global__ __launch_bounds__(256) void k_dense_encode(const float* __restrict__ 
 // in the main loop beyond addresses.
 // PASSES == 3 (float32-equivalent): both operands carry an fp16 residual plane (hi + lo), staged next to
 // the hi planes, and every tile takes 3 MFMAs (lo*hi + hi*lo + hi*hi), as the pointwise kernels do.
-template <int WM, int WN, int MT, int PASSES>
+// NSLOT: halo pieces a wave stages per chunk (3 covers every 3x3 stride-1 tiling; 9 the rest).
+template <int WM, int WN, int MT, int PASSES, int NSLOT>
 __global__ __launch_bounds__(kDnThreads, (MT == 4 || PASSES == 3 ? 2 : 4)) void k_dense_mfma(const DenseParams p) {
     static_assert(WM * WN == 8, "8 waves");
     constexpr int TH = WM * MT, BN = WN * 64, WT = BN * 128;  // WT: bytes of one tap's weight tile (one plane)
@@ -137,33 +139,55 @@ __global__ __launch_bounds__(kDnThreads, (MT == 4 || PASSES == 3 ? 2 : 4)) void 
 
     // ---- halo tile: piece q of a chunk = 8 consecutive halo pixels x 64 channels (fp16), one DMA.
     // lane -> (pixel pc*8 + lane/8, LDS slot lane%8); the slot holds 16-byte chunk slot ^ swz(pixel).
+    // A wave stages pieces wave, wave + 8, ...: the same pieces for every 64-channel chunk, so each piece's source
+    // address (pixel -> (ih, iw) -> bounds -> pointer: a division and ~40 VALU instructions) is worked out ONCE, before
+    // the loops; per chunk it only moves by 128 bytes.  (Profile r02c_vgg16: 67 VALU instructions per tap and wave,
+    // more issue cycles than the 16 MFMAs they surround.)
     const unsigned char* xen = reinterpret_cast<const unsigned char*>(p.xe) + (size_t)n * p.H * p.W * p.Cp * 2;
     const ptrdiff_t x_lo_off = PASSES == 3 ? reinterpret_cast<const unsigned char*>(p.xlo) - reinterpret_cast<const unsigned char*>(p.xe) : 0;
-    auto stage_x = [&](int pc, int chunk, int buf) {
+    const unsigned char* zp = p.zero_page + (lane & 7) * 16;
+    constexpr uint32_t kPad = 0xFFFFFFFFu;
+    uint32_t xoff[NSLOT];   // chunk-0 byte offset (from xen) of this lane's 16 bytes of piece slot j; kPad = padding (zero page)
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j) {
+        const int pc = wave + 8 * j;
         const int pix = pc * 8 + (lane >> 3);
         const int ih = pix / p.IW, iw = pix - ih * p.IW;
         const int gh = h_in0 + ih, gw = w_in0 + iw;
         const int c16 = (lane & 7) ^ (((pix >> 1) & 3) << 1);     // source chunk for this slot (dn_x_off's swizzle)
-        const int kbyte = chunk * 128 + c16 * 16;
-        const bool inb = pix < p.n_pix && (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W && kbyte < p.Cp * 2;
-        const unsigned char* src = inb ? xen + ((size_t)(gh * p.W + gw) * p.Cp) * 2 + kbyte : p.zero_page + (lane & 7) * 16;
+        const bool inb = pc < p.x_pieces && pix < p.n_pix && (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W;
+        xoff[j] = inb ? (uint32_t)((gh * p.W + gw) * p.Cp) * 2u + (uint32_t)c16 * 16u : kPad;   // < 2^31 (dense_mfma_applicable)
+    }
+    auto stage_x = [&](int j, int chunk, int buf) {   // piece slot j (compile-time after unrolling) of this wave
+        const int pc = wave + 8 * j;
+        const bool live = xoff[j] != kPad;            // Cp is a multiple of 64: every chunk is whole
+        const unsigned char* src = live ? xen + (xoff[j] + (uint32_t)chunk * 128u) : zp;
         glds16(src, xsb + (size_t)buf * PL * xbytes + (size_t)pc * 1024);
         if constexpr (PASSES == 3)
-            glds16(inb ? src + x_lo_off : src, xsb + ((size_t)buf * PL + 1) * xbytes + (size_t)pc * 1024);
+            glds16(live ? src + x_lo_off : src, xsb + ((size_t)buf * PL + 1) * xbytes + (size_t)pc * 1024);
     };
 
-    // ---- weight tap tile: BN/8 pieces of 1 KiB (channel tile, k-step), WN per wave
+    // ---- weight tap tile: BN/8 pieces of 1 KiB (channel tile, k-step), WN per wave.  The (tile, k-step) part of the
+    // address is fixed per wave; per (tap, chunk) only a wave-uniform offset moves.
     const int nt0 = nb * (BN / 16);
+    const unsigned char* wsrc[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int pc = wave * WN + j;                     // piece = (channel tile pc >> 1, k-step pc & 1)
+        int nt = nt0 + (pc >> 1);
+        nt = nt < p.n_tiles ? nt : p.n_tiles - 1;         // tiles past C_out: clamp (results never stored)
+        wsrc[j] = reinterpret_cast<const unsigned char*>(p.w) + ((size_t)nt * p.KS + (pc & 1)) * 1024 + (size_t)lane * 16;
+    }
+    const size_t w_tap_stride = (size_t)p.n_tiles * p.KS * 1024;
+    const ptrdiff_t w_lo_off = reinterpret_cast<const unsigned char*>(p.wlo) - reinterpret_cast<const unsigned char*>(p.w);
     auto stage_w = [&](int tap, int chunk, int buf) {
+        const size_t o = (size_t)tap * w_tap_stride + (size_t)chunk * 2048;   // wave-uniform
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
-            const int pc = wave * WN + j;                     // piece = (channel tile pc >> 1, k-step pc & 1)
-            int nt = nt0 + (pc >> 1);
-            nt = nt < p.n_tiles ? nt : p.n_tiles - 1;         // tiles past C_out: clamp (results never stored)
-            const size_t o = (((size_t)tap * p.n_tiles + nt) * p.KS + (size_t)chunk * 2 + (pc & 1)) * 1024 + (size_t)lane * 16;
-            glds16(reinterpret_cast<const unsigned char*>(p.w) + o, wbuf + (size_t)buf * PL * WT + (size_t)pc * 1024);
+            const int pc = wave * WN + j;
+            glds16(wsrc[j] + o, wbuf + (size_t)buf * PL * WT + (size_t)pc * 1024);
             if constexpr (PASSES == 3)
-                glds16(reinterpret_cast<const unsigned char*>(p.wlo) + o, wbuf + ((size_t)buf * PL + 1) * WT + (size_t)pc * 1024);
+                glds16(wsrc[j] + o + w_lo_off, wbuf + ((size_t)buf * PL + 1) * WT + (size_t)pc * 1024);
         }
     };
 
@@ -177,7 +201,9 @@ __global__ __launch_bounds__(kDnThreads, (MT == 4 || PASSES == 3 ? 2 : 4)) void 
     const int n_steps = n_chunks * n_taps;
     stage_w(0, 0, 0);
     if (n_steps > 1) stage_w(n_taps > 1 ? 1 : 0, n_taps > 1 ? 0 : 1, 1);
-    for (int pc = wave; pc < p.x_pieces; pc += 8) stage_x(pc, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j)
+        if (wave + 8 * j < p.x_pieces) stage_x(j, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -224,9 +250,9 @@ __global__ __launch_bounds__(kDnThreads, (MT == 4 || PASSES == 3 ? 2 : 4)) void 
             // a slice of the next chunk's halo; nothing on the last tap: its DMA would still be in flight
             // when the next chunk's first fragments are read
             if (more_chunks && tap + 1 < n_taps) {
-                for (int q = 0; q < p.x_per_tap; ++q) {
-                    const int pc = (tap * p.x_per_tap + q) * 8 + wave;
-                    if (pc < p.x_pieces) stage_x(pc, chunk + 1, xb ^ 1);
+#pragma unroll
+                for (int j = 0; j < NSLOT; ++j) {   // slot j goes out with tap j / x_per_tap (wave-uniform)
+                    if (j / p.x_per_tap == tap && wave + 8 * j < p.x_pieces) stage_x(j, chunk + 1, xb ^ 1);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -291,7 +317,7 @@ static bool dense_cfg_geometry(const slfp_conv2d_desc& d, const DenseCfg& c, int
     g->lds = (size_t)planes * (2 * (size_t)c.wn * 64 * 128 + 2 * (size_t)g->pieces * 1024);
     // MT 4 tilings hold 64 accumulator VGPRs + fragments: compiled for one workgroup per CU; the others for two
     g->occ = (c.mt == 4 || planes == 2) ? 1 : (g->lds <= 80 * 1024 ? 2 : 1);
-    return g->lds <= 160 * 1024;
+    return g->lds <= 160 * 1024 && ceil_div(g->pieces, 8) <= kMaxSlots;
 }
 
 // Relative cost of a tiling for this layer: workgroups per CU x padded tile MACs x a per-tiling
@@ -322,14 +348,15 @@ bool dense_mfma_applicable(const slfp_conv2d_desc& d, int passes) {
     if (d.groups != 1 || d.kh * d.kw <= 1 || d.dil_h != 1 || d.dil_w != 1) return false;
     if (d.stride_h != d.stride_w || d.stride_h > 2) return false;
     if (d.c_in % 4 || d.c_in < 16 || d.c_out % 4) return false;
-    if ((int64_t)d.h * d.w * (d.c_in + 31) >= (1ll << 30)) return false;
+    if ((int64_t)d.h * d.w * (d.c_in + 63) >= (1ll << 30)) return false;   // 32-bit byte offsets inside one image of the fp16 copy
     DenseGeom g;
     for (const DenseCfg& c : kDenseCfgs)
         if (dense_cfg_geometry(d, c, dense_planes(d, passes), &g)) return true;
     return false;  // (float32-equivalent mode: stride-2 halo tiles do not fit twice -> k_direct)
 }
 
-static int64_t dense_cp(const slfp_conv2d_desc& d) { return ceil_div(d.c_in, 32) * 32; }
+// channels of the pre-encoded copy: whole 64-channel chunks (the kernel stages 128-byte pixel rows without a tail case)
+static int64_t dense_cp(const slfp_conv2d_desc& d) { return ceil_div(d.c_in, 64) * 64; }
 
 // workspace = [256 B zero page][pre-encoded input: N*H*W*Cp fp16][its residual plane in float32-equivalent mode]
 static size_t dense_plane_bytes(const slfp_conv2d_desc& d) {
@@ -339,13 +366,19 @@ size_t dense_mfma_workspace_bytes(const slfp_conv2d_desc& d, int passes) {
     return 256 + (size_t)dense_planes(d, passes) * dense_plane_bytes(d);
 }
 
-template <int WM, int WN, int MT, int PASSES>
-static int launch_dense_tp(DenseParams& p, size_t lds, hipStream_t stream) {
-    auto fn = k_dense_mfma<WM, WN, MT, PASSES>;
+template <int WM, int WN, int MT, int PASSES, int NSLOT>
+static int launch_dense_tps(DenseParams& p, size_t lds, hipStream_t stream) {
+    auto fn = k_dense_mfma<WM, WN, MT, PASSES, NSLOT>;
     const int rc = raise_lds_limit(reinterpret_cast<const void*>(fn), 160 * 1024);  // once per (device, kernel)
     if (rc != SLFP_OK) return rc;
     hipLaunchKernelGGL(fn, dim3(p.nblocks), dim3(kDnThreads), lds, stream, p);
     return check_launch("slfp dense MFMA conv kernel");
+}
+
+template <int WM, int WN, int MT, int PASSES>
+static int launch_dense_tp(DenseParams& p, size_t lds, hipStream_t stream) {
+    return ceil_div(p.x_pieces, 8) <= 3 ? launch_dense_tps<WM, WN, MT, PASSES, 3>(p, lds, stream)
+                                         : launch_dense_tps<WM, WN, MT, PASSES, kMaxSlots>(p, lds, stream);
 }
 
 template <int WM, int WN, int MT>
