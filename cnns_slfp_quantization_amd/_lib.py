@@ -58,6 +58,11 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} is missing: the SLFP HIP extension is not built. "
             "Run `python -m cnns_slfp_quantization_amd.build` (needs hipcc). There is no CPU fallback.")
+    # The library is handed device pointers and streams that PyTorch created, so both must sit on ONE HIP runtime
+    # instance: import torch first, so that its bundled libamdhip64 is the one already in the process when the dynamic
+    # loader resolves this library's dependency (loading the library first pulls in /opt/rocm's copy, and the first launch
+    # then fails with "no ROCm-capable device is detected").
+    import torch  # noqa: F401
     L = ctypes.CDLL(LIB_PATH)
     vp, sz, ci, cf, i64 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_float, ctypes.c_int64
     dp = ctypes.POINTER(ConvDesc)

@@ -74,7 +74,7 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {  // 64 lanes x 
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-// Pre-pass: x (float32 NHWC) -> xe = fp16(16 * QA(x / Ka)), NHWC with C padded to a multiple of 32
+// Pre-pass: x (float32 NHWC) -> xe = fp16(16 * QA(x / Ka)), NHWC with C padded to a multiple of 64 (whole chunks)
 // and, inside every 32-channel group, 16-byte chunk j = channels {4j..4j+3, 16+4j..16+4j+3}: exactly
 // the 8 k-values lane-quarter j of a 16x16x32 MFMA B fragment holds.  One thread per chunk.
 // lo != nullptr (float32-equivalent mode): also writes the fp16 residual v - fp32(fp16(v)) to a second plane.

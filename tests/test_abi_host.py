@@ -66,7 +66,7 @@ def test_kernel_selection_and_sizes():
     dense.mfma_passes = _lib.MFMA_F16X3
     assert name(dense) == "dense_mfma_f16x3"                                     # float32-equivalent mode: hi + lo planes
     assert L.slfp_conv2d_wprep_bytes(ctypes.byref(dense)) == 2 * 9 * 64 * 32 * 2
-    assert L.slfp_conv2d_workspace_bytes(ctypes.byref(dense)) == 256 + 2 * (2 * 16 * 16 * 32 * 2)   # zero page + 2 fp16 planes, C padded to 32
+    assert L.slfp_conv2d_workspace_bytes(ctypes.byref(dense)) == 256 + 2 * (2 * 16 * 16 * 64 * 2)   # zero page + 2 fp16 planes, C padded to whole 64-channel chunks
     dense.stride_h = dense.stride_w = 2
     assert name(dense) == "direct_nhwc"                                          # stride-2 halo tiles do not fit twice
     dense.qbits = 7
