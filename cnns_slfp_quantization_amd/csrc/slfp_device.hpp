@@ -35,6 +35,9 @@ namespace slfp {
 #ifndef SLFP_NT_PW
 #define SLFP_NT_PW 0
 #endif
+#ifndef SLFP_NT_PWT
+#define SLFP_NT_PWT 0
+#endif
 #ifndef SLFP_NT_PW_STG
 #define SLFP_NT_PW_STG 2
 #endif
