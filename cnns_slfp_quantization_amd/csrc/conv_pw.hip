@@ -374,7 +374,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 4) void k_pw_til
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             if constexpr (KFULL) {
-                st[i] = ld_stream4<SLFP_NT_PW>(src[i] + t * 64);
+                st[i] = ld_stream4<SLFP_NT_PWT>(src[i] + t * 64);
             } else {
                 const int k = t * 64 + kc * 4;
                 const int kk = k < p.K ? t * 64 : p.K - 4 - kc * 4;  // clamp inside the row
