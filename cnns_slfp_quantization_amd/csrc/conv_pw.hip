@@ -48,34 +48,9 @@
 #include "slfp_device.hpp"
 #include "slfp_enc.hpp"
 #include "slfp_host.hpp"
+#include "conv_pw_params.hpp"
 
 namespace slfp {
-
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-typedef float floatx4 __attribute__((ext_vector_type(4)));
-
-struct PwParams {
-    const float* x;
-    const _Float16* whi;
-    const _Float16* wlo;
-    const float* bias;
-    float* y;
-    int64_t M;        // output pixels = N_img * Ho * Wo
-    int K, N;         // input / output channels
-    int KS;           // number of 32-deep k-steps in the blob (even)
-    int n_tiles;      // 16-row tiles in the blob (n_pad / 16)
-    int H, W, Ho, Wo, S;  // strided 1x1: input pixel = (oh*S, ow*S)
-    ScaleDiv sd;          // divides by Ka/16
-    float s1, s2;         // out = ((acc/256 + bias/s1/s2) * s1) * s2 ; s1x = s1/256
-    float s1x;
-    uint32_t m_blocks, n_blocks, nblocks;
-    int rb;               // k_pw_tiled: pixel rows a workgroup really owns (<= BM; the rest of its tile is padding)
-    PostOp post;
-    EncArgs enc;          // threshold table of fp16(16 * QA(x / Ka)) (TAB kernels; slfp_enc.hpp)
-};
-
-constexpr int kPwTab = (kEncEntries * 8 + 15) & ~15;   // LDS bytes of the threshold table
 
 // two float4 (k = kq*4.., 16 + kq*4..) -> one MFMA B fragment through the threshold table; NaNs not patched
 __device__ __forceinline__ half8 enc_frag(const float4 a, const float4 b, const EncArgs& e, const unsigned char* tb) {
@@ -113,23 +88,6 @@ __device__ __forceinline__ void encode4(const float4 v, const ScaleDiv sd, const
 
 __device__ __forceinline__ half8 join(const half4 a, const half4 b) {
     return half8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-}
-
-// out = ((acc * 2^-8 + bq) * s1) * s2 with the 2^-8 folded: ((acc + 256*bq) * (s1/256)) * s2
-__device__ __forceinline__ float4 epilogue(const floatx4 acc, const float4 bq256, const float s1x, const float s2) {
-    float4 r;
-    r.x = ((acc[0] + bq256.x) * s1x) * s2;
-    r.y = ((acc[1] + bq256.y) * s1x) * s2;
-    r.z = ((acc[2] + bq256.z) * s1x) * s2;
-    r.w = ((acc[3] + bq256.w) * s1x) * s2;
-    return r;
-}
-
-__device__ __forceinline__ float4 bias_q256(const PwParams& p, int n) {
-    if (!p.bias) return make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
-    return make_float4(256.f * ((bb.x / p.s1) / p.s2), 256.f * ((bb.y / p.s1) / p.s2),
-                       256.f * ((bb.z / p.s1) / p.s2), 256.f * ((bb.w / p.s1) / p.s2));
 }
 
 // ======================================================================================
@@ -316,11 +274,6 @@ __global__ __launch_bounds__(kStreamThreads) void k_pw_stream(const PwParams p) 
 // ======================================================================================
 // k_pw_tiled: X via a swizzled LDS tile (encoded once), W fragments straight from L2.
 // ======================================================================================
-__device__ __forceinline__ uint32_t lds_x_off(int row, int chunk16) {
-    // 128-byte rows (64 fp16); XOR swizzle so that the 16 rows a fragment read touches hit
-    // 16 distinct 16-byte slots (conflict-free ds_read_b128; cdna guide T2)
-    return (uint32_t)row * 128u + (uint32_t)((chunk16 ^ (row & 7)) << 4);
-}
 
 // KFULL: K is a multiple of 64 (no masking of the K tail).  Every global load in the main
 // loop is UNCONDITIONAL (rows beyond M are clamped to the last row and never stored, padded
@@ -329,7 +282,6 @@ __device__ __forceinline__ uint32_t lds_x_off(int row, int chunk16) {
 // in the middle of the MFMA block, draining the HBM loads it has just issued (r01c ISA).
 // STG: the epilogue goes through a per-wave LDS staging area so that every store instruction writes whole 256-byte runs
 // (4 pixel rows x the wave's 64 adjacent channels) instead of 64-byte pieces, with the nt hint (SLFP_NT_PW_STG).
-constexpr int kStgRow = 272;   // 256 B of a row's 64 channels + 16: the 16 rows' float4 writes spread over the banks
 template <int FMT, int PASSES, int WM, int WN, int MT, int NT, bool KFULL, bool TAB = false, bool STG = false>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 4) void k_pw_tiled(const PwParams p) {
     static_assert(!TAB || PASSES == 1, "the table form produces the single fp16 operand");
@@ -445,11 +397,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 4) void k_pw_til
         }
     };
 
+    SLFP_STAMP(0);
     __syncthreads();  // LUT visible
+    SLFP_STAMP(1);
     load_stage(0);
     encode_store(0);
     load_stage(KT > 1 ? 1 : 0);
     __syncthreads();
+    SLFP_STAMP(2);
 
     for (int t = 0; t + 1 < KT; ++t) {  // branch-free body
         const int buf = t & 1;
@@ -460,7 +415,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 4) void k_pw_til
         load_w(t * 2 + 1);
         mfma_step(buf, 1);
         __syncthreads();
+        SLFP_STAMP(3 + (t < 8 ? t : 8));
     }
+    SLFP_STAMP(12);
     {   // last stage: nothing left to prefetch
         const int t = KT - 1, buf = t & 1;
         load_w(t * 2);
@@ -484,6 +441,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 4) void k_pw_til
         }
         __syncthreads();
     }
+    SLFP_STAMP(13);
     if constexpr (STG) {
         unsigned char* stg = xs + 2 * (PASSES == 3 ? 2 : 1) * XBYTES + wave * (16 * kStgRow);   // private to this wave
         const uint64_t left = (uint64_t)(p.M - m0) * p.N * 4;
@@ -520,6 +478,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 4) void k_pw_til
                 __builtin_amdgcn_raw_buffer_store_b128(v, ry, so, 0, (SLFP_NT_PW_STG & 2) ? 2 : 0);
             }
         }
+        SLFP_STAMP(14);
+#ifdef SLFP_PW_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SLFP_STAMP(15);
+#endif
         return;
     }
 #pragma unroll
@@ -678,6 +641,9 @@ int launch_pointwise(const slfp_conv2d_desc& d, const ConvPlan& plan, const floa
     p.H = (int)d.h; p.W = (int)d.w; p.Ho = (int)plan.h_out; p.Wo = (int)plan.w_out; p.S = d.stride_h;
     p.M = d.n * plan.h_out * plan.w_out;
     p.sd = make_scale_div(d.ka, 4);  // x / (Ka/16) == 16 * (x / Ka)
+#ifdef SLFP_PW_STAMPS
+    { const char* e = getenv("SLFP_PW_DBG"); p.dbg = e ? reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 16)) : nullptr; }
+#endif
     p.enc.valid = 0;
     if (plan.passes == 1 && !getenv("SLFP_PW_NOTAB")) {   // SLFP_PW_NOTAB: per-call A/B switch (profiles/variants.py)
         if (const EncArgs* t = act_table(d.ka, plan.fmt_act, kEncF16P)) p.enc = *t;
