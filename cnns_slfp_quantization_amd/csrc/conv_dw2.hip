@@ -40,6 +40,7 @@ struct Dw2Params {
     uint32_t ntiles;      // N * tiles_h * tiles_w: tiles per channel group
     uint32_t nblocks;
     float ka, kw;
+    int nt_out;           // store the output with the nt hint (set by the launcher: outputs too large for the Infinity Cache)
     PostOp post;
     EncArgs enc;
 };
@@ -170,7 +171,11 @@ __global__ __launch_bounds__(kDw2Threads, 4) void k_dw3x3_tile(const float* __re
         const bool live = ocol_live && (oh0 + ohb + j * RPI) < p.Ho && (j * RPI + ohb) < TH && (ow0 + ow) < p.Wo;
         uint32_t so = live ? org + out_rel0 + (uint32_t)j * out_step : kOob;
         asm volatile("" : "+v"(so));
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned int, rr), ry, so, 0, (SLFP_NT_DW & 2) ? 2 : 0);
+        // nt for outputs the 256 MiB Infinity Cache cannot hold anyway (the store then does not displace what the next
+        // kernel reads); smaller outputs are stored normally so that the layer that consumes them finds them in the cache
+        typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
+        if (p.nt_out) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, rr), ry, so, 0, 2);
+        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, rr), ry, so, 0, 0);
     }
 }
 
@@ -202,6 +207,11 @@ int launch_dw3x3_tile(const slfp_conv2d_desc& d, const ConvPlan& plan, const flo
     p.ntiles = (uint32_t)ntiles;
     p.nblocks = (uint32_t)(ntiles * p.cgroups);
     p.ka = d.ka; p.kw = d.kw_scale;
+    {   // SLFP_NT_DW bit 1 enables the policy; SLFP_DW_NT_MIN_MB moves the threshold (experiment switch; 0 = always nt)
+        const char* e = getenv("SLFP_DW_NT_MIN_MB");
+        const int64_t min_mb = e ? atoll(e) : 120;
+        p.nt_out = ((SLFP_NT_DW & 2) && (int64_t)p.N * p.Ho * p.Wo * p.C * 4 >= (min_mb << 20)) ? 1 : 0;
+    }
     p.enc = *act_table(d.ka, plan.fmt_act, kEncF32);
     const int IH = (TH - 1) * S + 3;
     const size_t lds = kDw2Tab + (size_t)(2 * ((IH + 1) / 2)) * 16 * 32 * sizeof(float);

@@ -252,7 +252,8 @@ __global__ __launch_bounds__(kStreamThreads) void k_pw_stream(const PwParams p) 
                     const u32x4 v = *reinterpret_cast<const u32x4*>(stg + lane * 16 + h * 1024);
                     uint32_t so = ch_ok ? (uint32_t)((spx + 8 * h) * p.N + j0 * 16 + sch * 4) * 4u : 0xFFFFFFF0u;
                     asm volatile("" : "+v"(so));
-                    __builtin_amdgcn_raw_buffer_store_b128(v, ry, so, 0, (SLFP_NT_PW_STG & 2) ? 2 : 0);
+                    if (p.nt_out) __builtin_amdgcn_raw_buffer_store_b128(v, ry, so, 0, 2);
+                    else __builtin_amdgcn_raw_buffer_store_b128(v, ry, so, 0, 0);
                 }
             }
         } else {
@@ -475,7 +476,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 4) void k_pw_til
                 const bool ok = row < p.rb && m0 + row < p.M && n_st < p.N;
                 uint32_t so = ok ? (uint32_t)(row * p.N + n_st) * 4u : 0xFFFFFFF0u;
                 asm volatile("" : "+v"(so));
-                __builtin_amdgcn_raw_buffer_store_b128(v, ry, so, 0, (SLFP_NT_PW_STG & 2) ? 2 : 0);
+                if (p.nt_out) __builtin_amdgcn_raw_buffer_store_b128(v, ry, so, 0, 2);
+                    else __builtin_amdgcn_raw_buffer_store_b128(v, ry, so, 0, 0);
             }
         }
         SLFP_STAMP(14);
@@ -649,6 +651,12 @@ int launch_pointwise(const slfp_conv2d_desc& d, const ConvPlan& plan, const floa
         if (const EncArgs* t = act_table(d.ka, plan.fmt_act, kEncF16P)) p.enc = *t;
     }
     p.s1 = plan.s1; p.s2 = plan.s2; p.s1x = plan.s1 * (1.0f / 256.0f);
+    {   // staged stores always carry the nt hint: a size threshold as in conv_dw2.hip (plain stores for outputs that fit the
+        // Infinity Cache) measured 1.5 % SLOWER on the whole net here (profiles/ab_env_wn.sh); SLFP_PW_NT_MIN_MB: experiment switch
+        const char* e = getenv("SLFP_PW_NT_MIN_MB");
+        const int64_t min_mb = e ? atoll(e) : 0;
+        p.nt_out = ((SLFP_NT_PW_STG & 2) && p.M * p.N * 4 >= (min_mb << 20)) ? 1 : 0;
+    }
     if (plan.fmt_act == kFmtSfp7) return launch_pw<kFmtSfp7, 1>(p, plan, stream);  // exact in fp16
     if (plan.passes == 3) return launch_pw<kFmtAct8, 3>(p, plan, stream);
     return launch_pw<kFmtAct8, 1>(p, plan, stream);

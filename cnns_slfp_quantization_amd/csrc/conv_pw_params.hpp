@@ -27,6 +27,7 @@ struct PwParams {
     float s1x;
     uint32_t m_blocks, n_blocks, nblocks;
     int rb;               // k_pw_tiled: pixel rows a workgroup really owns (<= BM; the rest of its tile is padding)
+    int nt_out;           // staged (whole-line) stores carry the nt hint: outputs too large for the Infinity Cache
     PostOp post;
     EncArgs enc;          // threshold table of fp16(16 * QA(x / Ka)) (TAB kernels; slfp_enc.hpp)
 #ifdef SLFP_PW_STAMPS
