@@ -267,13 +267,15 @@ __global__ __launch_bounds__(256) void k_stem(const float* __restrict__ x, const
 // (the generic k_stem was VALU-bound: 1225 instructions per wave, profiles/r01c).
 // TAB: threshold-table quantizer (slfp_enc.hpp) and branch-free halo loads: a buffer descriptor over the image makes
 // out-of-image elements an out-of-range offset that reads 0, so the 7 loads of a thread issue back to back.
-template <int FMT, int KH, int KW, int C, int S, int O, bool TAB = false>
+// TH: output rows per workgroup (16 for the table variant: the 2 KiB table + 3.4 KiB of weights a workgroup stages are
+// then paid once per 32 KiB of output instead of once per 16 KiB).
+template <int FMT, int KH, int KW, int C, int S, int O, bool TAB = false, int TH = kStemTH>
 __global__ __launch_bounds__(256) void k_stem_fixed(const float* __restrict__ x, const float* __restrict__ wq,
                                                     const float* __restrict__ bias, float* __restrict__ y,
                                                     const StemParams p) {
-    constexpr int IH = (kStemTH - 1) * S + KH, IWC = ((kStemTW - 1) * S + KW) * C;
+    constexpr int IH = (TH - 1) * S + KH, IWC = ((kStemTW - 1) * S + KW) * C;
     constexpr int NW = KH * KW * C * O;
-    constexpr int L4 = O / 4, GROUPS = 256 / L4, P = kStemTH / (GROUPS / kStemTW);
+    constexpr int L4 = O / 4, GROUPS = 256 / L4, P = TH / (GROUPS / kStemTW);
     static_assert(GROUPS % kStemTW == 0 && P >= 1 && NW % 4 == 0, "unsupported stem shape");
     __shared__ __attribute__((aligned(16))) float sW[NW];
     __shared__ __attribute__((aligned(16))) float tile[IH * IWC];
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(256) void k_stem_fixed(const float* __restrict__ x,
     const int tw = b % p.tiles_w; b /= p.tiles_w;
     const int th = b % p.tiles_h; b /= p.tiles_h;
     const int n = b;
-    const int h_in0 = th * kStemTH * S - p.ph, w_in0 = tw * kStemTW * S - p.pw;
+    const int h_in0 = th * TH * S - p.ph, w_in0 = tw * kStemTW * S - p.pw;
     __syncthreads();
 
     {   // load + encode the halo tile: rows are contiguous in NHWC, one dword per lane
@@ -369,12 +371,12 @@ __global__ __launch_bounds__(256) void k_stem_fixed(const float* __restrict__ x,
     }
     const int gow = tw * kStemTW + col;
     if (gow >= p.Wo) return;
-    float* yb = y + (((size_t)n * p.Ho + th * kStemTH + row0) * p.Wo + gow) * O + c4 * 4;
+    float* yb = y + (((size_t)n * p.Ho + th * TH + row0) * p.Wo + gow) * O + c4 * 4;
     if (p.post.scale) {   // fused BN: the vectors once per thread (its own path: see conv_pw.hip, k_pw_tiled)
         const PostVec pv = post_load(p.post, c4 * 4);
 #pragma unroll
         for (int q = 0; q < P; ++q) {
-            if (th * kStemTH + row0 + q < p.Ho) {
+            if (th * TH + row0 + q < p.Ho) {
                 float4 r;
                 r.x = ((acc[q].x + bq.x) * p.s1) * p.s2;
                 r.y = ((acc[q].y + bq.y) * p.s1) * p.s2;
@@ -387,7 +389,7 @@ __global__ __launch_bounds__(256) void k_stem_fixed(const float* __restrict__ x,
     }
 #pragma unroll
     for (int q = 0; q < P; ++q) {
-        if (th * kStemTH + row0 + q < p.Ho) {
+        if (th * TH + row0 + q < p.Ho) {
             float4 r;
             r.x = ((acc[q].x + bq.x) * p.s1) * p.s2;
             r.y = ((acc[q].y + bq.y) * p.s1) * p.s2;
@@ -436,7 +438,10 @@ static int try_launch_stem(const slfp_conv2d_desc& d, const ConvPlan& plan, cons
         // the MobileNetV1 stem (nets_imgnet/mobilenetv1.py:44): fully specialised variant
         if (const EncArgs* t = act_table(d.ka, plan.fmt_act, kEncF32)) {
             p.enc = *t;
-            hipLaunchKernelGGL((k_stem_fixed<kFmtAct8, 3, 3, 3, 2, 32, true>), dim3(p.nblocks), dim3(256), 0, stream, x, wq_hwio, bias, y, p);
+            constexpr int TH = 16;
+            p.tiles_h = (int)ceil_div(p.Ho, TH);
+            p.nblocks = (uint32_t)((int64_t)p.N * p.tiles_h * p.tiles_w);
+            hipLaunchKernelGGL((k_stem_fixed<kFmtAct8, 3, 3, 3, 2, 32, true, TH>), dim3(p.nblocks), dim3(256), 0, stream, x, wq_hwio, bias, y, p);
         } else if (plan.fmt_act == kFmtAct8)
             hipLaunchKernelGGL((k_stem_fixed<kFmtAct8, 3, 3, 3, 2, 32>), dim3(p.nblocks), dim3(256), 0, stream, x, wq_hwio, bias, y, p);
         else
