@@ -233,6 +233,46 @@ def test_fuse_bn_relu_host_logic():
         fusion.fold_bn(m[1])  # training-mode BN cannot be folded
 
 
+def test_round2_host_logic_on_cpu():
+    """Host-side pieces added in round 2 that need no GPU: the depthwise+pointwise pairing (q_bit 32 passthrough blocks run
+    their two convs), unfuse() undoing it, the calibration files' text format (cifar100_train_eval.py:287-301), the
+    hipGraph wrapper refusing CPU inputs and training mode, and the plan key helper rejecting vector scales."""
+    import utils.conv2d_func as cf
+    from cnns_slfp_quantization_amd import calibration, fusion
+    from cnns_slfp_quantization_amd.conv2d_func import _scale_key
+    from cnns_slfp_quantization_amd.graph import GraphedModule
+    C = cf.conv2d_Q(32, 0.1, 0.2)
+    m = nn.Sequential(C(8, 8, 3, 0.1, 0.2, 1, 1, groups=8), nn.BatchNorm2d(8), nn.ReLU(inplace=True),
+                      C(8, 16, 1, 0.1, 0.2), nn.BatchNorm2d(16), nn.ReLU(inplace=True),
+                      C(16, 16, 3, 0.1, 0.2, 2, 1, groups=16), nn.BatchNorm2d(16), nn.ReLU(inplace=True),
+                      C(16, 4, 1, 0.1, 0.2), nn.BatchNorm2d(4)).eval()
+    for b in m:
+        if isinstance(b, nn.BatchNorm2d):
+            b.running_mean.normal_(); b.running_var.uniform_(0.5, 1.5); b.weight.data.uniform_(0.5, 1.5); b.bias.data.normal_()
+    x = torch.randn(2, 8, 9, 9)
+    with torch.no_grad():
+        y0 = m(x)
+        assert fusion.fuse_bn_relu(m, dw_pw=True) == 4
+        blocks = [b for b in m if isinstance(b, fusion.DwPwBlock)]
+        assert len(blocks) == 2
+        y1 = m(x)
+        assert torch.allclose(y0, y1, rtol=1e-5, atol=1e-5)
+        assert all(b._last_kernel is None for b in blocks)            # CPU / q_bit 32: the pair ran as its two convs
+        assert fusion.unfuse(m) == 4 and not any(isinstance(b, fusion.DwPwBlock) for b in m)
+        assert torch.equal(m(x), y0)
+    files = calibration.scale_files_text("mobilenetv1", {1: 2.5, 2: 3.0}, {28: 9.75}, {1: 0.5})
+    assert files["max_inout_mobilenetv1.txt"] == ("Layer 1 Max Absolute Input:\n2.5\n\nLayer 2 Max Absolute Input:\n3.0\n\n"
+                                                   "Layer 28 Max Absolute Output:\n9.75\n\n")
+    assert files["max_weight_mobilenetv1.txt"] == "Layer 1 Max Absolute weight:\n0.5\n\n"
+    assert calibration.scales_from_max({2: 31.0, 1: 15.5}) == [1.0, 2.0]
+    g = GraphedModule(m)
+    with pytest.raises(RuntimeError):
+        g(x)                                                          # CPU tensor: needs a ROCm device
+    assert _scale_key(torch.tensor(0.25), "Ka") == 0.25 and _scale_key(0.5, "Kw") == 0.5
+    with pytest.raises(ValueError):
+        _scale_key(torch.tensor([0.1, 0.2]), "Ka")
+
+
 def test_product_never_imports_the_oracle():
     """oracle/ is test infrastructure: only tests/, __graft_entry__ (build / smoke) and bench.py's cpu_baseline leg
     may import it.  A product path that routed through it would void every parity claim."""
