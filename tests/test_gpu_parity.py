@@ -322,15 +322,16 @@ def _check_against_oracle(lib, dev, N, C, H, O, k, s, p, g, qbits, passes, seed,
     tol = _tol(kern)
     kp, np_ = -(-C // 64) * 64, -(-O // 64) * 64
     stream_fits = kp <= 256 and kp * np_ * 2 <= 128 * 1024   # even widths need the LDS-resident stream kernel
-    assert (kern == "pw_mfma_f16x1") == (k == 1 and g == 1 and qbits == 8 and passes != 3 and C % 2 == 0 and O % 2 == 0
-                                         and (C % 4 + O % 4 == 0 or (stream_fits and C >= 8)))
+    assert (kern == "pw_mfma_f16x1") == (k == 1 and p == 0 and g == 1 and qbits == 8 and passes != 3 and C % 2 == 0 and O % 2 == 0
+                                         and (C % 4 + O % 4 == 0 or (stream_fits and C >= 8)))   # a padded 1x1 is not the pointwise family
     emax, el2 = rel_errors(got, ref)
     assert emax <= tol and el2 <= tol, (kern, (N, C, H, O, k, s), emax, el2)
     # elementwise view of the same comparison: fraction of outputs beyond 1e-3 * |ref|.  Float32-equivalent
     # kernels: only cancellation noise near zero crossings; single-pass fp16 MFMA: SURVEY section 7 measured 14 %.
     frac = elem_exceed_frac(got, ref)
     note_elem_stats(kern, got, ref)
-    assert frac <= (0.30 if kern.endswith("_f16x1") else 0.02), (kern, (N, C, H, O, k, s), frac)
+    if got.size >= 2048:   # a statistical bound (mean 13-14 % for single-pass fp16): meaningless on a few dozen outputs
+        assert frac <= (0.30 if kern.endswith("_f16x1") else 0.02), (kern, (N, C, H, O, k, s), frac)
     return kern, emax, el2
 
 
@@ -495,33 +496,38 @@ def test_randomized_geometries_vs_oracle(lib, dev):
     """Seeded random sweep over geometries (channels incl. odd / non-multiple-of-4 counts, kernel 1..7, stride 1..4,
     padding, depthwise / dense / small-C_in stems, bias, both precisions, all three MFMA modes): every kernel
     family and its fallbacks against the oracle, through the C ABI.  What the hand-picked cases might miss."""
-    rng = np.random.default_rng(20261004)
+    # SLFP_TEST_SOAK=<n>: n extra seeds of 500 geometries each (a soak run; the default suite runs the pinned seed only)
+    soak = int(os.environ.get("SLFP_TEST_SOAK", "0"))
     kinds = {}
-    for i in range(500):
-        kind = rng.choice(["dw", "pw", "dense", "stem", "any"])
-        k = int(rng.integers(1, 8))
-        s = int(rng.choice([1, 1, 2, 2, 3, 4]))
-        p = int(rng.integers(0, k // 2 + 2))
-        if kind == "dw":
-            C = int(rng.choice([4, 6, 8, 20, 24, 29, 30, 32, 58, 64, 100, 116])); O = C; g = C; k = 3; s = int(rng.choice([1, 2])); p = int(rng.integers(0, 3))
-        elif kind == "pw":
-            C = int(rng.choice([8, 12, 16, 24, 27, 32, 58, 64, 96, 130, 256, 320])); O = int(rng.choice([4, 10, 16, 30, 58, 64, 100, 128, 258, 520])); g = 1; k = 1; p = 0; s = int(rng.choice([1, 1, 2]))
-        elif kind == "dense":
-            C = int(rng.choice([16, 20, 32, 48, 64, 80, 128])); O = int(rng.choice([4, 16, 20, 64, 72, 128, 192, 260])); g = 1; k = int(rng.choice([2, 3, 3, 3, 5])); s = int(rng.choice([1, 1, 2]))
-            p = int(rng.integers(0, k // 2 + 1))
-        elif kind == "stem":
-            C = int(rng.choice([1, 2, 3, 3, 4])); O = int(rng.choice([4, 8, 16, 24, 32, 64, 96])); g = 1; k = int(rng.choice([2, 3, 3, 5, 7, 11])); p = int(rng.integers(0, k // 2 + 1))
-        else:
-            C = int(rng.choice([5, 6, 9, 12, 15, 18])); O = int(rng.choice([3, 6, 9, 12, 18])); g = int(rng.choice([1, 3])) if (C % 3 == 0 and O % 3 == 0) else 1
-        H = int(rng.integers(max(k, 2 * s) + 1, 41))
-        if H + 2 * p < k:
-            continue
-        qbits = int(rng.choice([8, 8, 7]))
-        passes = int(rng.choice([0, 0, 3])) if qbits == 8 else 0
-        bias = bool(rng.integers(0, 2))
-        N = int(rng.integers(1, 4))
-        kern, emax, el2 = _check_against_oracle(lib, dev, N, C, H, O, k, s, p, g, qbits, passes, seed=4000 + i, bias=bias)
-        kinds[kern] = kinds.get(kern, 0) + 1
+    for sweep in range(1 + soak):
+      rng = np.random.default_rng(20261004 + 7919 * sweep)
+      for i in range(500):
+          kind = rng.choice(["dw", "pw", "dense", "stem", "any"])
+          k = int(rng.integers(1, 8))
+          s = int(rng.choice([1, 1, 2, 2, 3, 4]))
+          p = int(rng.integers(0, k // 2 + 2))
+          if kind == "dw":
+              C = int(rng.choice([4, 6, 8, 20, 24, 29, 30, 32, 58, 64, 100, 116])); O = C; g = C; k = 3; s = int(rng.choice([1, 2])); p = int(rng.integers(0, 3))
+          elif kind == "pw":
+              C = int(rng.choice([8, 12, 16, 24, 27, 32, 58, 64, 96, 130, 256, 320])); O = int(rng.choice([4, 10, 16, 30, 58, 64, 100, 128, 258, 520])); g = 1; k = 1; p = 0; s = int(rng.choice([1, 1, 2]))
+          elif kind == "dense":
+              C = int(rng.choice([16, 20, 32, 48, 64, 80, 128])); O = int(rng.choice([4, 16, 20, 64, 72, 128, 192, 260])); g = 1; k = int(rng.choice([2, 3, 3, 3, 5])); s = int(rng.choice([1, 1, 2]))
+              p = int(rng.integers(0, k // 2 + 1))
+          elif kind == "stem":
+              C = int(rng.choice([1, 2, 3, 3, 4])); O = int(rng.choice([4, 8, 16, 24, 32, 64, 96])); g = 1; k = int(rng.choice([2, 3, 3, 5, 7, 11])); p = int(rng.integers(0, k // 2 + 1))
+          else:
+              C = int(rng.choice([5, 6, 9, 12, 15, 18])); O = int(rng.choice([3, 6, 9, 12, 18])); g = int(rng.choice([1, 3])) if (C % 3 == 0 and O % 3 == 0) else 1
+          H = int(rng.integers(max(k, 2 * s) + 1, 41))
+          if H + 2 * p < k:
+              continue
+          qbits = int(rng.choice([8, 8, 7]))
+          passes = int(rng.choice([0, 0, 3])) if qbits == 8 else 0
+          bias = bool(rng.integers(0, 2))
+          N = int(rng.integers(1, 4))
+          kern, emax, el2 = _check_against_oracle(lib, dev, N, C, H, O, k, s, p, g, qbits, passes, seed=4000 + i + 100000 * sweep, bias=bias)
+          kinds[kern] = kinds.get(kern, 0) + 1
+    if soak:
+        print(f"soak: {500 * (1 + soak)} geometries drawn, kernels reached: {kinds}")
     # the sweep must actually reach the families it is meant to cover
     for fam in ("dw3x3_nhwc", "repad+dw3x3_nhwc", "dense_mfma_f16x1", "dense_mfma_f16x3", "dense_mfma_f16_exact", "stem_small_mfma_f16x1",
                 "stem_mfma_f16x1", "direct_nhwc", "pw_mfma_f16x1", "pw_mfma_f16x3", "pw_mfma_f16_exact", "repad+pw_mfma_f16x1"):
