@@ -444,7 +444,7 @@ def test_large_kernel_stems_on_mfma_vs_oracle(lib, dev):
         assert kern in ("stem_nhwc", "direct_nhwc")
 
 
-@pytest.mark.parametrize("layer", [0, 1, 2, 3, 6, 14, 17, 18])
+@pytest.mark.parametrize("layer", list(range(19)) if int(os.environ.get("SLFP_TEST_SOAK", "0")) else [0, 1, 2, 3, 6, 14, 17, 18])
 def test_full_batch_256_sampled_images(lib, dev, layer):
     """At BASELINE.json's full size (batch 256, 224x224 ImageNet shapes) the oracle cannot
     run the whole tensor in seconds; images are independent units through the whole path,
