@@ -7,7 +7,8 @@ hot path's own traffic.  `fuse_bn_relu(model)` rewrites every such run inside an
 the BatchNorm2d's running statistics and affine are folded into a per-channel (scale, shift) that
 the HIP epilogue applies after the reference's (out*Ka)*Kw roundings (slfp_conv2d_fwd_post), and
 the BN / ReLU modules are replaced by nn.Identity.  Call it AFTER load_state_dict and model.eval().
-Nets that wire conv->bn by hand (ResNet-50 blocks) can use `fuse_pair(conv, bn, relu)`.
+Nets that wire conv->bn by hand in forward() (ResNet-50 blocks) use `fuse_named_bn(model, example_input)` (folds every
+conv<k>/bn<k> pair by name and verifies itself against the example input) or `fuse_pair(conv, bn, relu)` per pair.
 
 `fuse_dw_pw(model)` goes one step further for MobileNet blocks (second half): an adjacent
 [depthwise Conv2d_Q + BN + ReLU] -> [pointwise Conv2d_Q (+ BN + ReLU)] pair that libslfp_hip can run as ONE kernel
@@ -110,6 +111,60 @@ def unfuse(model):
                 conv._post = None
                 del conv._fused_modules
                 n += 1
+    return n
+
+
+def fuse_named_bn(model, example_input=None, rtol=2e-3):
+    """Blocks that wire conv -> bn by hand in their forward() (the reference's ResNet-50 Bottleneck,
+    nets_imgnet/resnet50.py:24-100: self.conv1 / self.bn1 / self.relu ...) cannot be rewritten by position, but they
+    follow the torchvision naming: every Conv2d_Q child called `<prefix>conv<suffix>` whose sibling `<prefix>bn<suffix>`
+    is an eval-mode BatchNorm2d of matching width gets that BatchNorm folded into its epilogue (the shared ReLU module
+    stays where it is: it is also applied after the residual add), and the BatchNorm child becomes nn.Identity.
+    Because a name is only a convention, pass `example_input`: the model's output before and after must agree within
+    `rtol` (tensor-relative) or everything is rolled back and a RuntimeError explains which check failed.
+    Returns the number of folded pairs; `unfuse_named_bn(model)` restores the modules."""
+    y0 = None
+    if example_input is not None:
+        with torch.no_grad():
+            y0 = model(example_input)
+    done = []
+    for parent in model.modules():
+        if isinstance(parent, nn.Sequential):
+            continue   # positional runs are fuse_bn_relu's job
+        for name, conv in list(parent._modules.items()):
+            if not _is_conv_q(conv) or conv._post is not None or "conv" not in name:
+                continue
+            bn_name = name.replace("conv", "bn", 1)
+            bn = parent._modules.get(bn_name)
+            if not isinstance(bn, nn.BatchNorm2d) or bn.training or bn.num_features != conv.out_channels:
+                continue
+            if conv.bias is not None and not getattr(conv, "_scaled_bias", False):
+                continue
+            fuse_pair(conv, bn, relu=False)
+            conv._named_bn = (parent, bn_name, bn)
+            parent._modules[bn_name] = nn.Identity()
+            done.append(conv)
+    if y0 is not None and done:
+        with torch.no_grad():
+            y1 = model(example_input)
+        err = float((y1 - y0).abs().max() / y0.abs().max().clamp_min(1e-30))
+        if not err <= rtol:
+            unfuse_named_bn(model)
+            raise RuntimeError(f"fuse_named_bn: the model's output moved by {err:.3e} (> {rtol}) -- some conv<k>/bn<k> pair is not "
+                               "applied as bn(conv(x)) in forward(); nothing was changed")
+    return len(done)
+
+
+def unfuse_named_bn(model):
+    """Undo fuse_named_bn."""
+    n = 0
+    for conv in model.modules():
+        if _is_conv_q(conv) and hasattr(conv, "_named_bn"):
+            parent, bn_name, bn = conv._named_bn
+            parent._modules[bn_name] = bn
+            conv._post = None
+            del conv._named_bn
+            n += 1
     return n
 
 

@@ -273,6 +273,47 @@ def test_round2_host_logic_on_cpu():
         _scale_key(torch.tensor([0.1, 0.2]), "Ka")
 
 
+def test_fuse_named_bn_on_hand_wired_blocks():
+    """fusion.fuse_named_bn: a torchvision-style residual block (conv1/bn1/relu, conv2/bn2, + identity, relu: the wiring of
+    nets_imgnet/resnet50.py:24-100) folds its BatchNorms by name, checks itself against an example input, and rolls back
+    when the naming convention lies (here: a block whose bn2 is applied BEFORE conv2)."""
+    import utils.conv2d_func as cf
+    from cnns_slfp_quantization_amd import fusion
+    C = cf.conv2d_Q(32, 0.1, 0.2)
+
+    class Block(nn.Module):
+        def __init__(self, honest=True):
+            super().__init__()
+            self.conv1 = C(8, 8, 3, 0.1, 0.2, 1, 1); self.bn1 = nn.BatchNorm2d(8)
+            self.conv2 = C(8, 8, 1, 0.1, 0.2); self.bn2 = nn.BatchNorm2d(8)
+            self.relu = nn.ReLU()
+            self.honest = honest
+
+        def forward(self, x):
+            out = self.relu(self.bn1(self.conv1(x)))
+            out = self.bn2(self.conv2(out)) if self.honest else self.conv2(self.bn2(out))
+            return self.relu(out + x)
+
+    x = torch.randn(2, 8, 6, 6)
+    for honest in (True, False):
+        m = nn.Sequential(Block(honest), Block(honest)).eval()
+        for b in m.modules():
+            if isinstance(b, nn.BatchNorm2d):
+                b.running_mean.normal_(); b.running_var.uniform_(0.5, 1.5); b.weight.data.uniform_(0.5, 1.5); b.bias.data.normal_()
+        with torch.no_grad():
+            y0 = m(x)
+            if honest:
+                assert fusion.fuse_named_bn(m, x) == 4
+                assert isinstance(m[0].bn1, nn.Identity) and m[0].conv1._post is not None and m[0].conv1._post[2] == 0
+                assert torch.allclose(m(x), y0, rtol=1e-5, atol=1e-5)
+                assert fusion.unfuse_named_bn(m) == 4 and isinstance(m[1].bn2, nn.BatchNorm2d)
+            else:
+                with pytest.raises(RuntimeError):
+                    fusion.fuse_named_bn(m, x)
+                assert isinstance(m[0].bn2, nn.BatchNorm2d) and m[0].conv2._post is None   # rolled back
+            assert torch.equal(m(x), y0)
+
+
 def test_product_never_imports_the_oracle():
     """oracle/ is test infrastructure: only tests/, __graft_entry__ (build / smoke) and bench.py's cpu_baseline leg
     may import it.  A product path that routed through it would void every parity claim."""

@@ -730,6 +730,50 @@ def test_plan_cache_follows_scales_shapes_and_layouts(dev):
             m(xs[0])
 
 
+def test_fuse_named_bn_on_residual_blocks_gpu(dev):
+    """ResNet-style hand-wired blocks (nets_imgnet/resnet50.py:24-100: conv1x1 -> bn -> relu -> conv3x3 -> bn -> relu ->
+    conv1x1 -> bn, + identity, relu) at Qbits 8 on the device: fuse_named_bn folds the three BatchNorms of each block into
+    the conv epilogues and its built-in example-input check passes; per block the fused result stays within the chained
+    bar of the stock modules, and unfuse restores them bit for bit."""
+    import utils.conv2d_func as cf
+    from cnns_slfp_quantization_amd import fusion
+    Ka, Kw = np.float64(0.25), np.float64(0.08)
+    C = cf.conv2d_Q(8, Kw, Ka)
+
+    class Bottleneck(torch.nn.Module):
+        def __init__(self, ch, mid):
+            super().__init__()
+            self.conv1 = C(ch, mid, 1, Kw, Ka); self.bn1 = torch.nn.BatchNorm2d(mid)
+            self.conv2 = C(mid, mid, 3, Kw, Ka, 1, 1); self.bn2 = torch.nn.BatchNorm2d(mid)
+            self.conv3 = C(mid, ch, 1, Kw, Ka); self.bn3 = torch.nn.BatchNorm2d(ch)
+            self.relu = torch.nn.ReLU()
+
+        def forward(self, x):
+            out = self.relu(self.bn1(self.conv1(x)))
+            out = self.relu(self.bn2(self.conv2(out)))
+            out = self.bn3(self.conv3(out))
+            return self.relu(out + x)
+
+    g = torch.Generator(device="cpu").manual_seed(11)
+    m = torch.nn.Sequential(Bottleneck(64, 16), Bottleneck(64, 32)).eval()
+    with torch.no_grad():
+        for b in m.modules():
+            if isinstance(b, torch.nn.BatchNorm2d):
+                b.running_mean.normal_(0.0, 0.1, generator=g); b.running_var.uniform_(0.6, 1.4, generator=g)
+                b.weight.uniform_(0.8, 1.4, generator=g); b.bias.normal_(0.05, 0.1, generator=g)
+    m = m.to(dev).to(memory_format=torch.channels_last)
+    x = torch.relu(torch.randn(4, 64, 14, 14, generator=g)).to(dev).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        y0 = m(x).clone()
+        assert fusion.fuse_named_bn(m, x, rtol=2e-2) == 6
+        y1 = m(x).clone()
+        assert all(isinstance(getattr(b, n), torch.nn.Identity) for b in m for n in ("bn1", "bn2", "bn3"))
+        e = rel_errors(y1.cpu().numpy(), y0.cpu().numpy())
+        assert max(e) <= 2e-2, e      # six chained requantizations downstream of BN folded into one fma (a few code flips)
+        assert fusion.unfuse_named_bn(m) == 6
+        assert torch.equal(m(x), y0)
+
+
 def test_bias_gradients_of_both_conv_classes(dev):
     """conv2d_Q hands the raw bias to F.conv2d (utils/conv2d_func.py:23), conv2d_Q_bias divides it by Ka and Kw first
     (:44): in both cases d(out)/d(bias) must be what autograd gives the reference composite (round 1 double-counted the
