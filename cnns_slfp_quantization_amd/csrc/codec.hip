@@ -5,6 +5,7 @@
 // stores.  Roofline: 8 B/element (quantize) or 5 B/element (encode) of HBM traffic.
 #include <cstdarg>
 #include <mutex>
+#include <map>
 #include <set>
 #include <utility>
 #include <cstdio>
@@ -40,17 +41,19 @@ int check_launch(const char* what) {
 const char* last_error_text() { return g_err; }
 
 int raise_lds_limit(const void* fn, size_t lds_bytes) {
-    if (lds_bytes <= 64 * 1024) return SLFP_OK;
+    // lds_bytes: the DYNAMIC LDS of the launch (kernels may add a few KiB of static LDS: the lookup tables)
+    if (lds_bytes <= 48 * 1024) return SLFP_OK;
     static std::mutex mu;
-    static std::set<std::pair<int, const void*>> done;
+    static std::map<std::pair<int, const void*>, size_t> raised;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return check_launch("hipGetDevice");
     std::lock_guard<std::mutex> lock(mu);
     const auto key = std::make_pair(dev, fn);
-    if (done.count(key)) return SLFP_OK;
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    const auto it = raised.find(key);
+    if (it != raised.end() && it->second >= lds_bytes) return SLFP_OK;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
         return check_launch("hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
-    done.insert(key);
+    raised[key] = lds_bytes;
     return SLFP_OK;
 }
 

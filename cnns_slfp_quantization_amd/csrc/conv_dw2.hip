@@ -61,7 +61,9 @@ __global__ __launch_bounds__(kDw2Threads, 4) void k_dw3x3_tile(const float* __re
     constexpr int NI = (IH + 1) / 2;            // load items per thread: rows 2i + (slot >> 4)
     constexpr int ROWB = 16 * 32 * 4;           // LDS bytes per halo row: 16 pixel slots x 32 channels
 
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // static LDS: the table sits at LDS address 0, a compile-time constant, so every table lookup is `ds_read_b64 v, bin`
+    // without the add of a (link-time) dynamic-LDS base that hipcc otherwise emits per lookup
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kDw2Tab + 2 * NI * ROWB];
     unsigned char* tile = smem + kDw2Tab;       // [2 * NI rows][16 slots][32 ch] float32
     enc_fill<kDw2Threads>(reinterpret_cast<uint2*>(smem), p.enc);
     const float r1 = p.enc.r1, lo = p.enc.lo, hi = p.enc.hi;
@@ -213,11 +215,9 @@ int launch_dw3x3_tile(const slfp_conv2d_desc& d, const ConvPlan& plan, const flo
         p.nt_out = ((SLFP_NT_DW & 2) && (int64_t)p.N * p.Ho * p.Wo * p.C * 4 >= (min_mb << 20)) ? 1 : 0;
     }
     p.enc = *act_table(d.ka, plan.fmt_act, kEncF32);
-    const int IH = (TH - 1) * S + 3;
-    const size_t lds = kDw2Tab + (size_t)(2 * ((IH + 1) / 2)) * 16 * 32 * sizeof(float);
 #define SLFP_DW2(SS, TT) \
-    do { if (post.scale) hipLaunchKernelGGL((k_dw3x3_tile<SS, TT, TT, true>), dim3(p.nblocks), dim3(kDw2Threads), lds, stream, x, wq9c, y, p); \
-         else hipLaunchKernelGGL((k_dw3x3_tile<SS, TT, TT, false>), dim3(p.nblocks), dim3(kDw2Threads), lds, stream, x, wq9c, y, p); } while (0)
+    do { if (post.scale) hipLaunchKernelGGL((k_dw3x3_tile<SS, TT, TT, true>), dim3(p.nblocks), dim3(kDw2Threads), 0, stream, x, wq9c, y, p); \
+         else hipLaunchKernelGGL((k_dw3x3_tile<SS, TT, TT, false>), dim3(p.nblocks), dim3(kDw2Threads), 0, stream, x, wq9c, y, p); } while (0)
     if (S == 2) SLFP_DW2(2, 7);
     else SLFP_DW2(1, 14);
 #undef SLFP_DW2

@@ -109,12 +109,15 @@ __global__ __launch_bounds__(kStreamThreads) void k_pw_stream(const PwParams p) 
     static_assert(!TAB || PASSES == 1, "the table form produces the single fp16 operand");
     static_assert(!STG || (TAB && !A8), "staged stores: table kernels with 16-byte channel alignment");
     constexpr int TABB = TAB ? kPwTab : 64;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t* sT = reinterpret_cast<uint32_t*>(smem);
-    _Float16* wl_hi = reinterpret_cast<_Float16*>(smem + TABB);
+    // The quantizer's table is STATIC LDS: its address is a compile-time constant, so a lookup is `ds_read_b64 v, bin`
+    // with no add of the (link-time) dynamic-LDS base -- hipcc emitted one VALU add per lookup (33 in the depthwise kernel).
+    __shared__ __attribute__((aligned(16))) unsigned char stab[TABB];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // everything else (sizes depend on the layer)
+    uint32_t* sT = reinterpret_cast<uint32_t*>(stab);
+    _Float16* wl_hi = reinterpret_cast<_Float16*>(smem);
     const int wfrags = p.n_tiles * p.KS;  // 1 KiB each
     _Float16* wl_lo = wl_hi + (size_t)wfrags * 512;
-    if constexpr (TAB) enc_fill<kStreamThreads>(reinterpret_cast<uint2*>(smem), p.enc);
+    if constexpr (TAB) enc_fill<kStreamThreads>(reinterpret_cast<uint2*>(stab), p.enc);
     else lut_fill<FMT>(sT);
     // W blob -> LDS (same fragment order), 16 bytes per thread per step
     for (int i = threadIdx.x; i < wfrags * 64; i += kStreamThreads) {
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(kStreamThreads) void k_pw_stream(const PwParams p) 
     // per-channel epilogue vectors -> LDS once per workgroup: [256 * bias/s1/s2 | post scale | post shift],
     // padded to the blob's channel count.  Read from global inside the sweep, the loads (and the 12 bias
     // divisions) sit on the critical path of every 16-byte store: +12-38 % on these layers (bench.py --post).
-    float* ep = reinterpret_cast<float*>(smem + TABB + (size_t)(PASSES == 3 ? 2 : 1) * wfrags * 1024);
+    float* ep = reinterpret_cast<float*>(smem + (size_t)(PASSES == 3 ? 2 : 1) * wfrags * 1024);
     const int n_pad = p.n_tiles * 16;
     unsigned char* stg = reinterpret_cast<unsigned char*>(ep + 3 * n_pad) + (threadIdx.x >> 6) * 2048;   // STG: this wave's 2 KiB
     const bool has_vec = p.bias != nullptr || p.post.scale != nullptr;   // wave-uniform
@@ -183,11 +186,11 @@ __global__ __launch_bounds__(kStreamThreads) void k_pw_stream(const PwParams p) 
 #pragma unroll
                 for (int c = 0; c < CH; ++c) {
                     any_nan |= enc_has_nan4(raw[c][0]) | enc_has_nan4(raw[c][1]);
-                    xh[c0 + c] = enc_frag(raw[c][0], raw[c][1], p.enc, smem);
+                    xh[c0 + c] = enc_frag(raw[c][0], raw[c][1], p.enc, stab);
                 }
                 if (__builtin_expect(any_nan, 0)) {   // NaN in -> NaN out; never taken on real activations
 #pragma unroll
-                    for (int c = 0; c < CH; ++c) xh[c0 + c] = enc_frag_nan(raw[c][0], raw[c][1], p.enc, smem);
+                    for (int c = 0; c < CH; ++c) xh[c0 + c] = enc_frag_nan(raw[c][0], raw[c][1], p.enc, stab);
                 }
             } else {
 #pragma unroll
@@ -295,10 +298,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 4) void k_pw_til
     static_assert(BM * 16 % T == 0, "staging must divide evenly");
     constexpr int XBYTES = BM * 128;
 
+    __shared__ __attribute__((aligned(16))) unsigned char stab[TABB];      // static: constant address (see k_pw_stream)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t* sT = reinterpret_cast<uint32_t*>(smem);
-    unsigned char* xs = smem + TABB;  // [2 buffers][hi, lo][BM rows][128 B]
-    if constexpr (TAB) enc_fill<T>(reinterpret_cast<uint2*>(smem), p.enc);
+    uint32_t* sT = reinterpret_cast<uint32_t*>(stab);
+    unsigned char* xs = smem;  // [2 buffers][hi, lo][BM rows][128 B]
+    if constexpr (TAB) enc_fill<T>(reinterpret_cast<uint2*>(stab), p.enc);
     else lut_fill<FMT>(sT);
 
     const uint32_t b = xcd_remap(blockIdx.x, p.nblocks);
@@ -344,7 +348,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 4) void k_pw_til
             const int row = (threadIdx.x >> 4) + i * (T / 16);
             const uint32_t off = lds_x_off(row, st_chunk) + st_sub;
             if constexpr (TAB) {
-                *reinterpret_cast<uint2*>(hi + off) = enc4_f16(st[i], p.enc.r1, p.enc.lo, p.enc.hi, smem);
+                *reinterpret_cast<uint2*>(hi + off) = enc4_f16(st[i], p.enc.r1, p.enc.lo, p.enc.hi, stab);
             } else {
                 half4 h, l;
                 encode4<FMT, PASSES>(st[i], p.sd, sT, h, l);
@@ -532,7 +536,7 @@ static int launch_tiled_k(PwParams& p, hipStream_t stream) {
         if (p.enc.valid) {
             if constexpr (NT == 4) {
                 if (!getenv("SLFP_PW_NOSTG")) {   // per-call A/B switch (profiles/variants.py)
-                    const size_t lds = kPwTab + (size_t)2 * BM * 128 + (size_t)(T / 64) * 16 * kStgRow;
+                    const size_t lds = (size_t)2 * BM * 128 + (size_t)(T / 64) * 16 * kStgRow;   // dynamic part (the table is static LDS)
                     auto fn = k_pw_tiled<FMT, 1, WM, WN, MT, NT, KFULL, true, true>;
                     int rc = set_lds_limit(reinterpret_cast<const void*>(fn), lds);
                     if (rc != SLFP_OK) return rc;
@@ -540,7 +544,7 @@ static int launch_tiled_k(PwParams& p, hipStream_t stream) {
                     return check_launch("slfp pointwise (tiled) kernel");
                 }
             }
-            const size_t lds = kPwTab + (size_t)2 * BM * 128;
+            const size_t lds = (size_t)2 * BM * 128;
             auto fn = k_pw_tiled<FMT, 1, WM, WN, MT, NT, KFULL, true>;
             int rc = set_lds_limit(reinterpret_cast<const void*>(fn), lds);
             if (rc != SLFP_OK) return rc;
@@ -548,7 +552,7 @@ static int launch_tiled_k(PwParams& p, hipStream_t stream) {
             return check_launch("slfp pointwise (tiled) kernel");
         }
     }
-    const size_t lds = 64 + (size_t)2 * (PASSES == 3 ? 2 : 1) * BM * 128;
+    const size_t lds = (size_t)2 * (PASSES == 3 ? 2 : 1) * BM * 128;   // dynamic part (the lookup table is static LDS)
     auto fn = k_pw_tiled<FMT, PASSES, WM, WN, MT, NT, KFULL>;
     int rc = set_lds_limit(reinterpret_cast<const void*>(fn), lds);
     if (rc != SLFP_OK) return rc;
@@ -572,8 +576,9 @@ static int launch_stream_ks(PwParams& p, hipStream_t stream) {
     const char* mk = getenv("SLFP_PW_STG_MAXKS");   // experiment switch
     const bool stg_ks = mk ? KS <= atoi(mk) : (KS <= 2 || KS == 8);
     const bool stg = tab && stg_ks && !(p.K % 4 || p.N % 4) && !getenv("SLFP_PW_NOSTG");
-    const size_t lds = (tab ? kPwTab : 64) + (size_t)(PASSES == 3 ? 2 : 1) * p.n_tiles * p.KS * 1024 + (size_t)3 * p.n_tiles * 16 * sizeof(float) +
-                       (stg ? (size_t)(kStreamThreads / 64) * 2048 : 0);
+    const size_t lds = (size_t)(PASSES == 3 ? 2 : 1) * p.n_tiles * p.KS * 1024 + (size_t)3 * p.n_tiles * 16 * sizeof(float) +
+                       (stg ? (size_t)(kStreamThreads / 64) * 2048 : 0);   // dynamic part; the table (2 KiB / 64 B) is static LDS
+    const size_t lds_total = lds + (tab ? kPwTab : 64);
     auto fn = (p.K % 4 || p.N % 4) ? k_pw_stream<FMT, PASSES, KS, false, true>
               : (p.K % 32 == 0)    ? k_pw_stream<FMT, PASSES, KS, true> : k_pw_stream<FMT, PASSES, KS, false>;
     if constexpr (PASSES == 1) {
@@ -584,7 +589,7 @@ static int launch_stream_ks(PwParams& p, hipStream_t stream) {
     int rc = set_lds_limit(reinterpret_cast<const void*>(fn), lds);
     if (rc != SLFP_OK) return rc;
     // persistent grid: as many workgroups per CU as LDS allows (<= 4), 256 CUs
-    int per_cu = (int)((160 * 1024) / lds);
+    int per_cu = (int)((160 * 1024) / lds_total);
     per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
     const int64_t groups = (p.M + 15) / 16;
     int64_t grid = 256 * per_cu;
