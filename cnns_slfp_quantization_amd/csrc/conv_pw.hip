@@ -413,14 +413,30 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 4) void k_pw_til
 
     for (int t = 0; t + 1 < KT; ++t) {  // branch-free body
         const int buf = t & 1;
+#ifdef SLFP_PW_STAMPS2   // diagnostic builds only: fine-grained stamps of stage 3 in slots 3..7 (profiles/stamps_fine.py)
+        if (t == 3) SLFP_STAMP(3);
+#endif
         load_w(t * 2);
         encode_store(buf ^ 1);                       // stage t+1 (fetched one stage ago) -> the other LDS buffer
         load_stage(t + 2 < KT ? t + 2 : KT - 1);     // stage t+2's HBM loads fly during the MFMAs (last: harmless re-read)
+#ifdef SLFP_PW_STAMPS2
+        if (t == 3) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); SLFP_STAMP(4); }
+#endif
         mfma_step(buf, 0);
+#ifdef SLFP_PW_STAMPS2
+        if (t == 3) { asm volatile("s_nop 0" : "+v"(acc[0][0]), "+v"(acc[3][3])); SLFP_STAMP(5); }
+#endif
         load_w(t * 2 + 1);
         mfma_step(buf, 1);
+#ifdef SLFP_PW_STAMPS2
+        if (t == 3) { asm volatile("s_nop 0" : "+v"(acc[0][0]), "+v"(acc[3][3])); SLFP_STAMP(6); }
+#endif
         __syncthreads();
+#ifdef SLFP_PW_STAMPS2
+        if (t == 3) SLFP_STAMP(7);
+#else
         SLFP_STAMP(3 + (t < 8 ? t : 8));
+#endif
     }
     SLFP_STAMP(12);
     {   // last stage: nothing left to prefetch
