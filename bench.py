@@ -242,8 +242,9 @@ def whole_net(specs, net, batch, dev, steps):
         out["batch8"] = {"error": str(e)[:200]}
     out["unit"] = "images/sec"
     out["note"] = ("whole MobileNetV1-224 incl. BN/ReLU/pool/fc through the drop-in modules, 1 GPU, batch %d; fused_dw_pw = "
-                   "fused_bn_relu + the depthwise/pointwise pairs libslfp_hip can run as one kernel (bit-identical; see DESIGN.md for "
-                   "why it is not yet the faster of the two); fused_hipgraph = the faster net replayed as one hipGraph" % batch)
+                   "fused_bn_relu + the depthwise/pointwise pairs run as ONE kernel where that measured at least as fast as two (the "
+                   "32-channel stride-1 block; options.dwpw_all forces every supported pair; bit-identical either way, DESIGN.md "
+                   "section 4); fused_hipgraph = the faster net replayed as one hipGraph" % batch)
     return out
 
 

@@ -54,6 +54,8 @@ class _Options:
     output_layout = "same"           # "same": follow the input's memory format; "nhwc": always channels_last
     eager_stash = False              # True: materialise input_q / weight_q on every forward like the reference
     plan_cache = True                # False: rebuild descriptor / shapes / workspace on every call (host-overhead A/B)
+    dwpw_all = False                 # True: fusion.DwPwBlock uses the one-kernel form wherever the library supports it,
+                                     # not only where it measured faster than two kernels
 
 
 options = _Options()

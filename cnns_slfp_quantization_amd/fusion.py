@@ -189,6 +189,10 @@ class DwPwBlock(nn.Module):
               and not self.training and not torch.is_grad_enabled() and options.mfma_passes in (_lib.MFMA_DEFAULT, _lib.MFMA_F16X1)
               and dw.q_bit in (8, 7) and dw._post is not None and dw._post[0] is not None and not (int(dw._post[2]) & 2)
               and pw._post is not None and not (int(pw._post[2]) & 2))
+        # measured (profiles/dwpw_bench.py): the one-kernel form only pays on the 32-channel stride-1
+        # block; the wider ones run faster as two kernels until the kernel's next version.  options.dwpw_all forces it.
+        if ok and not getattr(options, "dwpw_all", False):
+            ok = dw.in_channels == 32 and tuple(dw.stride) == (1, 1)
         if not ok:
             self._last_kernel = None
             return pw(dw(x))

@@ -6,6 +6,7 @@ import os, sys
 import numpy as np, torch, torch.nn as nn
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import utils.conv2d_func as cf
+cf.options.dwpw_all = True
 from cnns_slfp_quantization_amd import fusion, layer_specs
 dev = torch.device("cuda", 0)
 specs = layer_specs.conv_layers("mobilenetv1_imagenet224")

@@ -803,6 +803,7 @@ def test_fused_depthwise_pointwise_block_is_bit_identical(dev):
     would-be input (dw output through the stock modules, quantized) is what the oracle's quantizer gives, bit-exact."""
     import utils.conv2d_func as cf
     from cnns_slfp_quantization_amd import fusion
+    cf.options.dwpw_all = True   # every supported pair, not only the ones where the one-kernel form is the faster choice
     g = torch.Generator(device=dev).manual_seed(5)
     #        C    N   stride  H   batch
     cases = [(32, 64, 1, 28, 3), (64, 128, 2, 30, 2), (128, 128, 1, 14, 2), (128, 256, 2, 28, 2), (32, 64, 1, 33, 2), (64, 64, 2, 15, 1)]
@@ -839,6 +840,7 @@ def test_fused_depthwise_pointwise_block_is_bit_identical(dev):
             mid_fused = m[2](m[1](m[0](x)))   # BN-fused depthwise alone
         q_got = so.quantize(mid_fused.permute(0, 2, 3, 1).contiguous().cpu().numpy(), np.float32(Ka2), so.FMT_ACT8)
         assert np.mean(q_ref.view(np.uint32) != q_got.view(np.uint32)) <= 2e-4   # folded-BN fma vs stock BN: rare one-step flips
+    cf.options.dwpw_all = False
 
 
 # ------------------------------------------------------------------ whole net (BASELINE config 1)
