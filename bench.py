@@ -190,6 +190,18 @@ def whole_net(specs, net, batch, dev, steps):
             torch.cuda.synchronize()
             out[tag] = round(batch * steps / (time.perf_counter() - t0), 1)
         out["dw_pw_blocks_one_kernel"] = sum(1 for m in model.modules() if isinstance(m, fusion.DwPwBlock) and m._last_kernel)
+        # later measurements in one process run a little faster (clocks / allocator warm): measure the two-kernel net again
+        # AFTER the paired one so that the comparison is not an ordering artefact, and keep its better number
+        fusion.unfuse_dw_pw(model)
+        for _ in range(2):
+            model(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            model(x)
+        torch.cuda.synchronize()
+        out["fused_bn_relu"] = max(out["fused_bn_relu"], round(batch * steps / (time.perf_counter() - t0), 1))
+        fusion.fuse_dw_pw(model)
         if out["fused_dw_pw"] < out["fused_bn_relu"]:   # replay the faster of the two nets below
             fusion.unfuse_dw_pw(model)
             out["hipgraph_net"] = "fused_bn_relu"

@@ -56,6 +56,7 @@ class _Options:
     plan_cache = True                # False: rebuild descriptor / shapes / workspace on every call (host-overhead A/B)
     dwpw_all = False                 # True: fusion.DwPwBlock uses the one-kernel form wherever the library supports it,
                                      # not only where it measured faster than two kernels
+    dwpw_pairs = {(32, 1)}           # (depthwise channels, stride) pairs that run as one kernel by default
 
 
 options = _Options()

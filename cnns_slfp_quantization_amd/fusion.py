@@ -192,7 +192,7 @@ class DwPwBlock(nn.Module):
         # measured (profiles/dwpw_bench.py): the one-kernel form only pays on the 32-channel stride-1
         # block; the wider ones run faster as two kernels until the kernel's next version.  options.dwpw_all forces it.
         if ok and not getattr(options, "dwpw_all", False):
-            ok = dw.in_channels == 32 and tuple(dw.stride) == (1, 1)
+            ok = (dw.in_channels, int(dw.stride[0])) in getattr(options, "dwpw_pairs", {(32, 1)})
         if not ok:
             self._last_kernel = None
             return pw(dw(x))
