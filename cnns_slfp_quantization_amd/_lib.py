@@ -24,6 +24,7 @@ SYMBOLS = (
     "slfp_linear_workspace_bytes", "slfp_linear_fwd", "slfp_linear_prepare_weights", "slfp_linear_fwd_prepared",
     "slfp_nchw_to_nhwc_f32", "slfp_nhwc_to_nchw_f32", "slfp_debug_div_mismatches",
     "slfp_debug_enc_mismatches", "slfp_enc_table_ok", "slfp_dwpw_supported", "slfp_dwpw_fwd",
+    "slfp_conv2d_codes_supported", "slfp_conv2d_fwd_codes", "slfp_debug_code_mismatches",
 )
 
 
@@ -38,6 +39,11 @@ class ConvDesc(ctypes.Structure):
         ("qbits", ctypes.c_int32), ("ka", ctypes.c_float), ("kw_scale", ctypes.c_float),
         ("mfma_passes", ctypes.c_int32), ("reserved", ctypes.c_int32),
     ]
+
+
+class ConvIo(ctypes.Structure):
+    """struct slfp_conv2d_io: float32 or 1-byte codes on either side of a layer (slfp_conv2d_fwd_codes)"""
+    _fields_ = [("x_codes", ctypes.c_int32), ("y_codes", ctypes.c_int32), ("y_ka", ctypes.c_float), ("y_qbits", ctypes.c_int32)]
 
 
 class SlfpError(RuntimeError):
@@ -94,6 +100,9 @@ def load():
         "slfp_enc_table_ok": (ci, [cf, ci]),
         "slfp_dwpw_supported": (ci, [dp, dp]),
         "slfp_dwpw_fwd": (ci, [dp, dp, vp, vp, vp, vp, ci, vp, vp, vp, vp, ci, vp, vp]),
+        "slfp_conv2d_codes_supported": (ci, [dp, ctypes.POINTER(ConvIo), ci, ci]),
+        "slfp_conv2d_fwd_codes": (ci, [dp, ctypes.POINTER(ConvIo), vp, vp, vp, vp, vp, ci, vp, vp]),
+        "slfp_debug_code_mismatches": (ci, [cf, ci, vp, vp]),
     }
     assert set(sigs) == set(SYMBOLS)
     for name, (res, args) in sigs.items():

@@ -57,6 +57,20 @@ int raise_lds_limit(const void* fn, size_t lds_bytes) {
     return SLFP_OK;
 }
 
+int device_cu_count() {
+    static std::mutex mu;
+    static std::map<int, int> cus;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 256; }
+    std::lock_guard<std::mutex> lock(mu);
+    const auto it = cus.find(dev);
+    if (it != cus.end()) return it->second;
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; }
+    cus[dev] = n;
+    return n;
+}
+
 constexpr int kThreads = 256;
 
 // MODE 0: y = Q(x/scale) float32; MODE 1: code byte.

@@ -2,6 +2,7 @@
 // descriptor validation, kernel selection, weight preparation, dispatch.
 #include <cstring>
 #include "slfp_device.hpp"
+#include "slfp_codes.hpp"
 #include "slfp_host.hpp"
 
 namespace slfp {
@@ -399,6 +400,66 @@ int slfp_conv2d_fwd_post(const slfp_conv2d_desc* d, const float* x, const void* 
     if (d->y_layout == SLFP_LAYOUT_NCHW) rc = slfp_nhwc_to_nchw_f32(y_nhwc, y, d->n, d->c_out, p.h_out, p.w_out, stream);
     return rc;
 }
+
+}  // extern "C"
+
+// ---- 1-byte activation codes between layers (include/slfp.h; csrc/slfp_codes.hpp) ----
+static int codes_route(const slfp_conv2d_desc* d, const slfp_conv2d_io* io, bool has_bias, int relu, ConvPlan* p) {
+    // 0: unsupported; 1: depthwise on codes; 2: pointwise on codes; 3: image stem with code output
+    if (!d || !io) return 0;
+    if (make_plan(d, p) != SLFP_OK) return 0;
+    if (d->x_layout != SLFP_LAYOUT_NHWC || d->y_layout != SLFP_LAYOUT_NHWC) return 0;
+    if ((relu & ~(SLFP_POST_RELU | SLFP_POST_LAYEROUT)) != 0 || (relu & SLFP_POST_LAYEROUT)) return 0;
+    if (io->y_codes) {
+        if (io->y_qbits != 8 && io->y_qbits != 7) return 0;
+        if (!(io->y_ka > 0.f) || !scale_div_ok(io->y_ka)) return 0;
+        if (!enc_table(io->y_ka, io->y_qbits == 8 ? kFmtAct8 : kFmtSfp7, kEncCode)->valid) return 0;
+    }
+    if (long_encode_forced()) return 0;
+    if (io->x_codes) {
+        if (dwc_applicable(*d, *p, has_bias ? reinterpret_cast<const float*>(1) : nullptr, relu)) return 1;
+        if (pwc_applicable(*d, *p, relu, io->y_codes != 0)) return 2;
+        return 0;
+    }
+    if (io->y_codes && stem_codes_applicable(*d, *p, relu)) return 3;
+    return 0;
+}
+
+extern "C" int slfp_conv2d_codes_supported(const slfp_conv2d_desc* d, const slfp_conv2d_io* io, int has_bias, int relu) {
+    ConvPlan p;
+    return codes_route(d, io, has_bias != 0, relu, &p) != 0 ? 1 : 0;
+}
+
+extern "C" int slfp_conv2d_fwd_codes(const slfp_conv2d_desc* d, const slfp_conv2d_io* io, const void* x, const void* wprep,
+                                     const float* bias, const float* post_scale, const float* post_shift, int relu, void* y,
+                                     void* stream) {
+    if (!d || !io) return fail(SLFP_ERR_BAD_ARG, "slfp_conv2d_fwd_codes: null descriptor");
+    ConvPlan p;
+    int rc = make_plan(d, &p);
+    if (rc != SLFP_OK) return rc;
+    if (!x || !wprep || !y) return fail(SLFP_ERR_BAD_ARG, "slfp_conv2d_fwd_codes: null pointer");
+    if ((post_scale == nullptr) != (post_shift == nullptr))
+        return fail(SLFP_ERR_BAD_ARG, "slfp_conv2d_fwd_codes: post_scale and post_shift must be given together");
+    if (!aligned16(x) || !aligned16(y) || !aligned16(wprep) || (bias && !aligned16(bias)) ||
+        (post_scale && (!aligned16(post_scale) || !aligned16(post_shift))))
+        return fail(SLFP_ERR_ALIGNMENT, "slfp_conv2d_fwd_codes: pointers must be 16-byte aligned");
+    const int route = codes_route(d, io, bias != nullptr, relu, &p);
+    if (route == 0)
+        return fail(SLFP_ERR_UNSUPPORTED, "slfp_conv2d_fwd_codes: this layer / io combination has no code-path kernel "
+                                          "(slfp_conv2d_codes_supported); use slfp_conv2d_fwd_post");
+    const PostOp post{post_scale, post_shift, (relu & SLFP_POST_RELU) ? 1 : 0, 0};
+    const int y_fmt = io->y_qbits == 7 ? kFmtSfp7 : kFmtAct8;
+    hipStream_t st = as_stream(stream);
+    if (route == 1)
+        return launch_dwc(*d, p, reinterpret_cast<const uint8_t*>(x), reinterpret_cast<const float*>(wprep), post, y,
+                          io->y_codes != 0, io->y_ka, y_fmt, st);
+    if (route == 2)
+        return launch_pwc(*d, p, reinterpret_cast<const uint8_t*>(x), wprep, bias, post, y, io->y_codes != 0, io->y_ka, y_fmt, st);
+    const CodeIo cio{false, true, io->y_ka, y_fmt};
+    return launch_stem_codes(*d, p, reinterpret_cast<const float*>(x), reinterpret_cast<const float*>(wprep), bias, post, y, cio, st);
+}
+
+extern "C" {
 
 size_t slfp_linear_workspace_bytes(int64_t batch, int64_t in_f, int64_t out_f) {
     slfp_conv2d_desc d;

@@ -10,6 +10,7 @@
 // loads, broadcast through L1) straight from global memory.
 #include "slfp_device.hpp"
 #include "slfp_enc.hpp"
+#include "slfp_codes.hpp"
 #include "slfp_host.hpp"
 
 namespace slfp {
@@ -159,6 +160,8 @@ struct StemParams {
     PostOp post;
     uint32_t nblocks;
     EncArgs enc;         // threshold table of QA(x / Ka) (k_stem_fixed<.., TAB>; slfp_enc.hpp)
+    EncArgsCompact enc_out;  // YC: code table of the consumer's Ka (kEncCode; slfp_codes.hpp)
+    int sgn, fmt_out;        // YC: codes carry a sign (no ReLU in front of the quantizer); their format
 };
 
 template <int FMT>
@@ -269,7 +272,8 @@ __global__ __launch_bounds__(256) void k_stem(const float* __restrict__ x, const
 // out-of-image elements an out-of-range offset that reads 0, so the 7 loads of a thread issue back to back.
 // TH: output rows per workgroup (16 for the table variant: the 2 KiB table + 3.4 KiB of weights a workgroup stages are
 // then paid once per 32 KiB of output instead of once per 16 KiB).
-template <int FMT, int KH, int KW, int C, int S, int O, bool TAB = false, int TH = kStemTH>
+// YC: the output leaves as the 1-byte codes of the next layer's QA(. / Ka) (slfp_codes.hpp): a lane's 4 channels are one dword.
+template <int FMT, int KH, int KW, int C, int S, int O, bool TAB = false, int TH = kStemTH, bool YC = false>
 __global__ __launch_bounds__(256) void k_stem_fixed(const float* __restrict__ x, const float* __restrict__ wq,
                                                     const float* __restrict__ bias, float* __restrict__ y,
                                                     const StemParams p) {
@@ -280,8 +284,10 @@ __global__ __launch_bounds__(256) void k_stem_fixed(const float* __restrict__ x,
     __shared__ __attribute__((aligned(16))) float sW[NW];
     __shared__ __attribute__((aligned(16))) float tile[IH * IWC];
     __shared__ __attribute__((aligned(16))) uint32_t sT[TAB ? 2 * (kEncEntries + 1) : 16];
+    __shared__ __attribute__((aligned(16))) unsigned char senc[YC ? ((kEncEntries * 8 + 15) & ~15) : 16];
     if constexpr (TAB) enc_fill<256>(reinterpret_cast<uint2*>(sT), p.enc);
     else lut_fill<FMT>(sT);
+    if constexpr (YC) enc_fill_compact<256>(reinterpret_cast<uint2*>(senc), p.enc_out);
     for (int i = threadIdx.x * 4; i < NW; i += 256 * 4)
         *reinterpret_cast<float4*>(sW + i) = *reinterpret_cast<const float4*>(wq + i);
 
@@ -371,6 +377,35 @@ __global__ __launch_bounds__(256) void k_stem_fixed(const float* __restrict__ x,
     }
     const int gow = tw * kStemTW + col;
     if (gow >= p.Wo) return;
+    if constexpr (YC) {
+        uint8_t* yc = reinterpret_cast<uint8_t*>(y) + (((size_t)n * p.Ho + th * TH + row0) * p.Wo + gow) * O + c4 * 4;
+        const PostVec pv = post_load(p.post, c4 * 4);
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            if (th * TH + row0 + q < p.Ho) {
+                float4 r;
+                r.x = ((acc[q].x + bq.x) * p.s1) * p.s2;
+                r.y = ((acc[q].y + bq.y) * p.s1) * p.s2;
+                r.z = ((acc[q].z + bq.z) * p.s1) * p.s2;
+                r.w = ((acc[q].w + bq.w) * p.s1) * p.s2;
+                r = post_apply_v(r, p.post, pv);
+                uint32_t code = enc4_code<false>(r, p.enc_out.r1, p.enc_out.lo, p.enc_out.hi, senc);
+                if (p.sgn) {
+                    const float rs[4] = {r.x, r.y, r.z, r.w};
+                    uint32_t out = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        uint32_t cc = (code >> (8 * k)) & 0xFFu;
+                        cc = (cc == 1u || rs[k] != rs[k]) ? cc : (cc | ((__float_as_uint(rs[k]) >> 24) & 0x80u));
+                        out |= cc << (8 * k);
+                    }
+                    code = p.fmt_out == kFmtSfp7 ? ((out & 0x3F3F3F3Fu) | ((out & 0x80808080u) >> 1)) : out;
+                }
+                *reinterpret_cast<uint32_t*>(yc + (uint32_t)(q * p.Wo * O)) = code;
+            }
+        }
+        return;
+    }
     float* yb = y + (((size_t)n * p.Ho + th * TH + row0) * p.Wo + gow) * O + c4 * 4;
     if (p.post.scale) {   // fused BN: the vectors once per thread (its own path: see conv_pw.hip, k_pw_tiled)
         const PostVec pv = post_load(p.post, c4 * 4);
@@ -412,7 +447,7 @@ bool stem_applicable(const slfp_conv2d_desc& d) {
 
 // Returns SLFP_OK if it launched, 1 if this geometry is not a stem (caller falls back).
 static int try_launch_stem(const slfp_conv2d_desc& d, const ConvPlan& plan, const float* x, const float* wq_hwio,
-                           const float* bias, const PostOp& post, float* y, hipStream_t stream) {
+                           const float* bias, const PostOp& post, float* y, hipStream_t stream, const CodeIo* io = nullptr) {
     const int O = (int)d.c_out, C = (int)d.c_in;
     if (!stem_applicable(d)) return 1;
     StemParams p;
@@ -441,6 +476,15 @@ static int try_launch_stem(const slfp_conv2d_desc& d, const ConvPlan& plan, cons
             constexpr int TH = 16;
             p.tiles_h = (int)ceil_div(p.Ho, TH);
             p.nblocks = (uint32_t)((int64_t)p.N * p.tiles_h * p.tiles_w);
+            if (io && io->y_codes) {   // output as the next layer's codes (slfp_conv2d_fwd_codes)
+                const EncArgs* tc = enc_table(io->y_ka, io->y_fmt, kEncCode);
+                if (!tc->valid) return fail(SLFP_ERR_UNSUPPORTED, "stem (codes): no code table for the consumer's scale %g", (double)io->y_ka);
+                p.enc_out = enc_compact(*tc);
+                p.sgn = post.relu ? 0 : 1;
+                p.fmt_out = io->y_fmt;
+                hipLaunchKernelGGL((k_stem_fixed<kFmtAct8, 3, 3, 3, 2, 32, true, TH, true>), dim3(p.nblocks), dim3(256), 0, stream, x, wq_hwio, bias, y, p);
+                return check_launch("slfp stem conv kernel (3x3x3 s2 -> 32, codes out)");
+            }
             hipLaunchKernelGGL((k_stem_fixed<kFmtAct8, 3, 3, 3, 2, 32, true, TH>), dim3(p.nblocks), dim3(256), 0, stream, x, wq_hwio, bias, y, p);
         } else if (plan.fmt_act == kFmtAct8)
             hipLaunchKernelGGL((k_stem_fixed<kFmtAct8, 3, 3, 3, 2, 32>), dim3(p.nblocks), dim3(256), 0, stream, x, wq_hwio, bias, y, p);
@@ -453,6 +497,20 @@ static int try_launch_stem(const slfp_conv2d_desc& d, const ConvPlan& plan, cons
     else
         hipLaunchKernelGGL((k_stem<kFmtSfp7>), dim3(p.nblocks), dim3(256), lds, stream, x, wq_hwio, bias, y, p);
     return check_launch("slfp stem conv kernel");
+}
+
+// The MobileNetV1 stem (float32 image in) writing the next layer's codes: only the fully specialised table variant.
+bool stem_codes_applicable(const slfp_conv2d_desc& d, const ConvPlan& plan, int post_flags) {
+    if (plan.family != kDirect || !stem_applicable(d) || (post_flags & SLFP_POST_LAYEROUT)) return false;
+    if (!(d.kh == 3 && d.kw == 3 && d.c_in == 3 && d.stride_h == 2 && d.c_out == 32 && plan.fmt_act == kFmtAct8)) return false;
+    if ((int64_t)d.h * d.w * d.c_in >= (1ll << 30)) return false;
+    return act_table(d.ka, plan.fmt_act, kEncF32) != nullptr;
+}
+
+int launch_stem_codes(const slfp_conv2d_desc& d, const ConvPlan& plan, const float* x, const float* wq_hwio, const float* bias,
+                      const PostOp& post, void* y, const CodeIo& io, hipStream_t stream) {
+    const int rc = try_launch_stem(d, plan, x, wq_hwio, bias, post, reinterpret_cast<float*>(y), stream, &io);
+    return rc == 1 ? fail(SLFP_ERR_UNSUPPORTED, "stem (codes): unsupported geometry") : rc;
 }
 
 int launch_direct(const slfp_conv2d_desc& d, const ConvPlan& plan, const float* x, const float* wq_hwio,

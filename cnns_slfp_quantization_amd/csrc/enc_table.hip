@@ -14,6 +14,7 @@
 #include <cstring>
 #include "slfp_device.hpp"
 #include "slfp_enc.hpp"
+#include "slfp_codes.hpp"
 #include "slfp_host.hpp"
 
 namespace slfp {
@@ -45,6 +46,25 @@ uint32_t host_quant_bits(float x, float d, int fmt) {
     return v | (f2u(x) & 0x80000000u);
 }
 
+// unsigned extended code (include/slfp.h: SLFP_FMT_EXT) of the class with float32 value bits `vbits` -- the byte
+// slfp_encode_f32(x, Ka, fmt | SLFP_FMT_EXT) yields for every x of that class, minus the sign bit (csrc/slfp_device.hpp:
+// quant_code).  -1: not a value of the format.
+int host_ext_code(uint32_t vbits, int fmt) {
+    const uint32_t a = vbits & 0x7FFFFFFFu;
+    if (a == 0u) return 1;                    // exact zero
+    if (a == kBitsTiny) return 0;             // the +-1e-10 class
+    const int E = (int)(a >> 23) - 127;
+    if (E < -3 || E > 3) return -1;
+    if (fmt == kFmtSfp7) {
+        if (a & 0x000FFFFFu) return -1;
+        return ((E + 4) << 3) | (int)((a >> 20) & 7u);   // 15.0 = 1.875 * 2^3 is the canonical top code 0x3F
+    }
+    if (a == kBitsClamp8) return 2;           // the clamp literal 15.3216496 (the computed top value 15.3216524 is 0x7F)
+    for (int m = 0; m < 16; ++m)
+        if ((a & 0x7FFFFFu) == kT16h[m]) return ((E + 4) << 4) | m;
+    return -1;
+}
+
 // float32 -> fp16 bits, round to nearest even (the conversion `(_Float16)v` performs on the device)
 static uint32_t f32_to_f16_bits(float f) {
     _Float16 h = (_Float16)f;
@@ -68,6 +88,7 @@ struct Builder {
     uint32_t val(uint32_t xb) const {   // representation of Q(|x|/Ka)
         const uint32_t v = host_quant_bits(u2f(xb), d, fmt);
         if (rep == kEncF32) return v;
+        if (rep == kEncCode) return (uint32_t)host_ext_code(v, fmt);   // 0xFFFFFFFF if v is not a class value: build() then fails
         return f32_to_f16_bits(16.0f * u2f(v));
     }
     // smallest pattern in [a, b] with pred true (pred is false..true monotone on [a, b]; pred(b) must hold)
@@ -121,7 +142,9 @@ static bool build(float ka, int fmt, int rep, EncArgs* out) {
             if (B.val(m) != expect) return false;
         }
         const uint32_t c = p & 0xFFu;
+        if (rep == kEncCode && (va > 0x7Fu || vb > 0x7Fu)) return false;
         if (rep == kEncF32) out->e[c] = make_uint2(X, va);
+        else if (rep == kEncCode) out->e[c] = make_uint2(X, va | (vb << 8));
         else out->e[c] = make_uint2(X, va | (vb << 16));
         // with the linear float32 layout the upper class of bin p is read from entry p + 1
         have_prev = (rep == kEncF32) && (X != kEncNever);
@@ -199,6 +222,57 @@ __global__ __launch_bounds__(256) void k_enc_check(const ScaleDiv sd, const EncA
     if (bad) atomicAdd(out, bad);
 }
 
+// ---- exhaustive self-check of the code representation (slfp_codes.hpp): all 2^32 inputs -----------------------------
+// out[0] = #x whose byte from enc4_code_fmt<FMT, true> differs from quant_code<FMT>(x / Ka, ext) -- the byte
+//          slfp_encode_f32(.., fmt | SLFP_FMT_EXT) stores;  out[1] = the same for the unsigned variant (what a producer
+//          with a ReLU epilogue runs) over the inputs it can see: x >= +0 and x == -0;
+// out[2] = #codes c (0..255, counted once) whose decode-table entries differ from decode_bits / fp16(16 * decode_bits).
+template <int FMT>
+__global__ __launch_bounds__(256) void k_code_check(const ScaleDiv sd, const EncArgs t, unsigned long long* __restrict__ out) {
+    __shared__ uint32_t sT[16];
+    __shared__ __attribute__((aligned(16))) uint2 sE[kEncEntries + 1];
+    __shared__ __attribute__((aligned(16))) uint32_t sD32[256], sD16[256];
+    lut_fill<kFmtW8>(sT);   // identity table for decode_bits
+    enc_fill<256>(sE, t);
+    dec_fill<FMT, kDecF32, 256>(sD32);
+    dec_fill<FMT, kDecF16D, 256>(sD16);
+    __syncthreads();
+    const unsigned char* tb = reinterpret_cast<const unsigned char*>(sE);
+    unsigned long long bad_s = 0, bad_u = 0, bad_d = 0;
+    if (blockIdx.x == 0) {   // decode tables against the long-form decoder (codec.hip uses decode_bits)
+        const uint32_t c = threadIdx.x;
+        const uint32_t ref = decode_bits<FMT>(c, true, sT);
+        const _Float16 h = (_Float16)(16.0f * __uint_as_float(ref));
+        uint16_t hb;
+        __builtin_memcpy(&hb, &h, 2);
+        const uint32_t packed = c | (c << 8) | (c << 16) | (c << 24);
+        const float4 f = dec4_f32(packed, reinterpret_cast<const unsigned char*>(sD32));
+        const uint2 g = dec4_f16(packed, reinterpret_cast<const unsigned char*>(sD16));
+        const bool ok = __float_as_uint(f.x) == ref && __float_as_uint(f.y) == ref && __float_as_uint(f.z) == ref &&
+                        __float_as_uint(f.w) == ref && g.x == ((uint32_t)hb | ((uint32_t)hb << 16)) && g.y == g.x;
+        if (!ok) ++bad_d;
+    }
+    const uint64_t stride = (uint64_t)gridDim.x * 256 * 4;
+    for (uint64_t i = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < (1ull << 32); i += stride) {
+        float4 x;
+        x.x = __uint_as_float((uint32_t)i); x.y = __uint_as_float((uint32_t)i + 1u);
+        x.z = __uint_as_float((uint32_t)i + 2u); x.w = __uint_as_float((uint32_t)i + 3u);
+        const float xs[4] = {x.x, x.y, x.z, x.w};
+        const uint32_t cs = enc4_code_fmt<FMT, true>(x, t.r1, t.lo, t.hi, tb);
+        const uint32_t cu = enc4_code_fmt<FMT, false>(x, t.r1, t.lo, t.hi, tb);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t ux = __float_as_uint(xs[e]);
+            const uint32_t ref = quant_code<FMT>(__float_as_uint(div_const(xs[e], sd)), ux, true);
+            if (((cs >> (8 * e)) & 0xFFu) != ref) ++bad_s;
+            if ((ux < 0x80000000u || ux == 0x80000000u) && ((cu >> (8 * e)) & 0xFFu) != ref) ++bad_u;
+        }
+    }
+    if (bad_s) atomicAdd(out, bad_s);
+    if (bad_u) atomicAdd(out + 1, bad_u);
+    if (bad_d) atomicAdd(out + 2, bad_d);
+}
+
 }  // namespace slfp
 
 using namespace slfp;
@@ -228,4 +302,20 @@ extern "C" int slfp_enc_table_ok(float scale_div, int fmt) {
     if (fmt != SLFP_FMT_ACT8 && fmt != SLFP_FMT_SFP7) return 0;
     if (!(scale_div > 0.f) || !scale_div_ok(scale_div)) return 0;
     return (enc_table(scale_div, fmt, kEncF32)->valid && enc_table(scale_div, fmt, kEncF16P)->valid) ? 1 : 0;
+}
+
+// The producer side of the 1-byte inter-layer format (csrc/slfp_codes.hpp): sweeps ALL 2^32 float32 inputs and compares
+// the table-driven code with the long form behind slfp_encode_f32(.., fmt | SLFP_FMT_EXT); also checks both decode tables.
+extern "C" int slfp_debug_code_mismatches(float scale_div, int fmt, unsigned long long* out3, void* stream) {
+    if (!out3 || !(scale_div > 0.f)) return fail(SLFP_ERR_BAD_ARG, "slfp_debug_code_mismatches: bad argument");
+    if (fmt != SLFP_FMT_ACT8 && fmt != SLFP_FMT_SFP7) return fail(SLFP_ERR_BAD_ARG, "slfp_debug_code_mismatches: fmt must be ACT8 or SFP7");
+    if (!scale_div_ok(scale_div)) return fail(SLFP_ERR_UNSUPPORTED, "scale must be within [1e-30, 1e30]");
+    const EncArgs* t = enc_table(scale_div, fmt, kEncCode);
+    if (!t->valid) return fail(SLFP_ERR_UNSUPPORTED, "no code table for scale %g (one-step-per-bin property not provable)", (double)scale_div);
+    hipStream_t st = as_stream(stream);
+    if (hipMemsetAsync(out3, 0, 3 * sizeof(unsigned long long), st) != hipSuccess) return check_launch("hipMemsetAsync");
+    const ScaleDiv sd = make_scale_div(scale_div);
+    if (fmt == SLFP_FMT_ACT8) hipLaunchKernelGGL((k_code_check<kFmtAct8>), dim3(256 * 16), dim3(256), 0, st, sd, *t, out3);
+    else hipLaunchKernelGGL((k_code_check<kFmtSfp7>), dim3(256 * 16), dim3(256), 0, st, sd, *t, out3);
+    return check_launch("slfp code-table self-check kernel");
 }

@@ -89,6 +89,28 @@ int launch_dw3x3_tile(const slfp_conv2d_desc& d, const ConvPlan& p, const float*
                       const PostOp& post, float* y, hipStream_t stream);
 int launch_pointwise(const slfp_conv2d_desc& d, const ConvPlan& p, const float* x, const void* wfrag,
                      const float* bias, const PostOp& post, float* y, hipStream_t stream);
+// ---- 1-byte activation codes between layers (slfp_codes.hpp; slfp_conv2d_fwd_codes) ----
+// How a layer's input arrives and its output leaves: float32, or the extended codes of QA(. / ka) in format fmt.
+struct CodeIo {
+    bool x_codes;     // x holds uint8 codes of QA(x / d.ka) (format of d.qbits) instead of float32
+    bool y_codes;     // y receives uint8 codes of QA(out / y_ka) in format y_fmt instead of float32
+    float y_ka;
+    int y_fmt;        // kFmtAct8 | kFmtSfp7
+};
+// Number of compute units of the current device (cached per device; 256 on MI355X): persistent grids are sized from it.
+int device_cu_count();
+// pointwise on codes (conv_pw_codes.hpp): codes in, codes or float32 out; the SAME prepared blob as launch_pointwise
+bool pwc_applicable(const slfp_conv2d_desc& d, const ConvPlan& p, int post_flags, bool y_codes);
+int launch_pwc(const slfp_conv2d_desc& d, const ConvPlan& p, const uint8_t* x, const void* wfrag, const float* bias,
+               const PostOp& post, void* y, bool y_codes, float y_ka, int y_fmt, hipStream_t stream);
+// the MobileNetV1 image stem with code output (conv_direct.hip)
+bool stem_codes_applicable(const slfp_conv2d_desc& d, const ConvPlan& p, int post_flags);
+int launch_stem_codes(const slfp_conv2d_desc& d, const ConvPlan& p, const float* x, const float* wq_hwio, const float* bias,
+                      const PostOp& post, void* y, const CodeIo& io, hipStream_t stream);
+// depthwise 3x3 on codes (conv_dwc.hip): codes in, codes or float32 out
+bool dwc_applicable(const slfp_conv2d_desc& d, const ConvPlan& p, const float* bias, int post_flags);
+int launch_dwc(const slfp_conv2d_desc& d, const ConvPlan& p, const uint8_t* x, const float* wq9c, const PostOp& post,
+               void* y, bool y_codes, float y_ka, int y_fmt, hipStream_t stream);
 int launch_direct(const slfp_conv2d_desc& d, const ConvPlan& p, const float* x, const float* wq_hwio,
                   const float* bias, const PostOp& post, float* y, hipStream_t stream);
 bool stem_applicable(const slfp_conv2d_desc& d);  // direct family: the small-C_in stem kernel takes it

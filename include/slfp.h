@@ -157,6 +157,36 @@ int slfp_dwpw_fwd(const slfp_conv2d_desc* dw, const slfp_conv2d_desc* pw, const 
                   const float* bias_pw, const float* post2_scale, const float* post2_shift, int relu2, float* y,
                   void* stream);
 
+/* ---- inter-layer activations as 1-byte codes ("... + next layer's encode") ---------------------------
+ * Every Conv2d_Q of the reference nets feeds BatchNorm2d -> ReLU -> the next Conv2d_Q, whose first step is
+ * input_q = quantize_act(input / Ka) (utils/conv2d_func.py:21; nets_imgnet/mobilenetv1.py:24-33).  With `y_codes` the
+ * producer applies the CONSUMER's quantizer in its epilogue and stores, per element, the byte
+ *     slfp_encode_f32(out, y_ka, fmt(y_qbits) | SLFP_FMT_EXT)
+ * instead of the float32 value; with `x_codes` a layer reads such bytes (written for ITS Ka and qbits) in place of the
+ * float32 tensor and skips its own quantizer.  Classes and values are the same as on the float32 interface, so a chain
+ * of layers linked this way returns bit for bit what slfp_conv2d_fwd_post returns layer by layer (single-pass MFMA mode /
+ * SFP<3,3>), while activations cross HBM as 1 B per element instead of 4.  NaN has no code (it becomes 0x00, as in
+ * slfp_encode_f32).  Both tensors are NHWC; x, y and wprep 16-byte aligned; wprep is the blob of
+ * slfp_conv2d_prepare_weights for the same descriptor.  Supported: 3x3 depthwise (x_codes), 1x1 (x_codes; C_in a
+ * multiple of 32, C_out of 16 with y_codes), and the 3x3 stride-2 RGB stem -> 32 channels (float32 in, y_codes):
+ * every layer of nets_imgnet/mobilenetv1.py:43-57.  slfp_conv2d_codes_supported answers 1 / 0 without device work. */
+typedef struct slfp_conv2d_io {
+    int32_t x_codes;  /* 0: x is float32 (as slfp_conv2d_fwd); 1: x is uint8 codes of QA(. / d->ka), format of d->qbits */
+    int32_t y_codes;  /* 0: y is float32; 1: y receives uint8 codes of QA(out / y_ka) in the format of y_qbits        */
+    float y_ka;       /* float32(Ka) of the layer that will read y                                                   */
+    int32_t y_qbits;  /* its q_bit: 8 = SLFP<3,4>, 7 = SFP<3,3>                                                       */
+} slfp_conv2d_io;
+int slfp_conv2d_codes_supported(const slfp_conv2d_desc* d, const slfp_conv2d_io* io, int has_bias, int relu);
+/* post_scale / post_shift / relu as in slfp_conv2d_fwd_post (SLFP_POST_LAYEROUT is not supported here). */
+int slfp_conv2d_fwd_codes(const slfp_conv2d_desc* d, const slfp_conv2d_io* io, const void* x, const void* wprep,
+                          const float* bias, const float* post_scale, const float* post_shift, int relu, void* y,
+                          void* stream);
+/* Self-check of the producer side: sweeps ALL 2^32 float32 inputs on the device; out3[0] = inputs whose table-driven code
+ * (signed variant) differs from slfp_encode_f32(.., fmt | SLFP_FMT_EXT), out3[1] = the same for the unsigned variant a
+ * producer with a ReLU epilogue runs (inputs >= +0 and -0), out3[2] = code bytes whose decode-table entries (float32 and
+ * fp16 operand) differ from slfp_decode_f32.  All three must be 0.  fmt: SLFP_FMT_ACT8 or SLFP_FMT_SFP7. */
+int slfp_debug_code_mismatches(float scale_div, int fmt, unsigned long long* out3, void* stream);
+
 /* ---- linear: replaces Linear_Q.forward (utils/conv2d_func.py:60-65) -------------------
  * out = linear(QA(x/Ka), QW(w/Kw), bias/Kw/Ka) * Kw * Ka   (note the Kw-first order).
  * x: [batch, in_f] row-major, w: [out_f, in_f] row-major, bias: [out_f] or NULL.  The weights

@@ -1,0 +1,256 @@
+"""GPU (MI355X): the 1-byte inter-layer activation format (second half; include/slfp.h
+slfp_conv2d_fwd_codes; csrc/slfp_codes.hpp), through the C ABI.
+
+What the reference does between two quantized convolutions (nets_imgnet/mobilenetv1.py:24-33 + utils/conv2d_func.py:21):
+    y = relu(bn(conv_q(x)));   input_q = quantize_act(y / Ka_next)
+The code path stores slfp_encode_f32(y, Ka_next, fmt | EXT) in the producer and decodes in the consumer.  The bars:
+  * PRODUCER: the bytes layer i writes are equal to slfp_encode_f32(float32 output of the fused layer i, Ka_{i+1}, ..);
+  * CONSUMER: layer i+1's output from the bytes is BIT-IDENTICAL to its output from the float32 tensor;
+  * the code tables are exhaustively checked on the device (all 2^32 inputs) against the long form.
+The float32-interface kernels themselves are pinned to the oracle / the reference's golden vectors in test_gpu_parity.py.
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import slfp_oracle as so
+
+pytestmark = pytest.mark.gpu
+SOAK = int(os.environ.get("SLFP_TEST_SOAK", "0") or 0)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from cnns_slfp_quantization_amd import _lib
+    L = _lib.load()  # raises if libslfp_hip.so is missing: no fallback
+    assert L.slfp_device_count() >= 1
+    return _lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _desc(lib, s, n, qbits):
+    return lib.ConvDesc(n=n, c_in=s.c_in, h=s.h, w=s.w, c_out=s.c_out, kh=s.k[0], kw=s.k[1], stride_h=s.stride[0],
+                        stride_w=s.stride[1], pad_h=s.pad[0], pad_w=s.pad[1], dil_h=1, dil_w=1, groups=s.groups,
+                        x_layout=lib.LAYOUT_NHWC, y_layout=lib.LAYOUT_NHWC, qbits=qbits, ka=float(np.float32(s.Ka)),
+                        kw_scale=float(np.float32(s.Kw)), mfma_passes=lib.MFMA_F16X1, reserved=0)
+
+
+def _encode(lib, x, ka, fmt):
+    c = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    lib.check(lib.load().slfp_encode_f32(x.data_ptr(), c.data_ptr(), x.numel(), float(np.float32(ka)), fmt | lib.FMT_EXT, _stream()))
+    return c
+
+
+class _Layer:
+    """One Conv2d_Q layer of a layer table with random weights, folded-BN vectors and prepared weights."""
+
+    def __init__(self, lib, s, n, qbits, dev, gen, post=True, relu=True):
+        L = lib.load()
+        self.s, self.n, self.qbits, self.relu = s, n, qbits, relu
+        self.d = _desc(lib, s, n, qbits)
+        fan = (s.c_in // s.groups) * s.k[0] * s.k[1]
+        self.w = torch.randn((s.c_out, s.c_in // s.groups, s.k[0], s.k[1]), generator=gen, device=dev)
+        self.w.mul_(min(5.0 * s.Kw, 3.0 * (2.0 / fan) ** 0.5 + 2.0 * s.Kw))
+        self.blob = torch.empty(L.slfp_conv2d_wprep_bytes(ctypes.byref(self.d)), dtype=torch.uint8, device=dev)
+        lib.check(L.slfp_conv2d_prepare_weights(ctypes.byref(self.d), self.w.data_ptr(), self.blob.data_ptr(), None, _stream()))
+        self.scale = (torch.rand(s.c_out, generator=gen, device=dev) + 0.5) if post else None
+        self.shift = (torch.randn(s.c_out, generator=gen, device=dev) * 0.3) if post else None
+        self.kernel = L.slfp_conv2d_kernel_name(ctypes.byref(self.d)).decode()
+
+    def out_shape(self):
+        return (self.n, self.s.h_out, self.s.w_out, self.s.c_out)
+
+    def fwd_f32(self, lib, x):
+        """the float32 interface: slfp_conv2d_fwd_post"""
+        L = lib.load()
+        y = torch.empty(self.out_shape(), device=x.device)
+        ws_n = L.slfp_conv2d_workspace_bytes(ctypes.byref(self.d))
+        ws = torch.empty(ws_n, dtype=torch.uint8, device=x.device) if ws_n else None
+        lib.check(L.slfp_conv2d_fwd_post(ctypes.byref(self.d), x.data_ptr(), self.blob.data_ptr(), None,
+                                         self.scale.data_ptr() if self.scale is not None else None,
+                                         self.shift.data_ptr() if self.shift is not None else None,
+                                         1 if self.relu else 0, y.data_ptr(), None, ws.data_ptr() if ws is not None else None, _stream()))
+        return y
+
+    def fwd_codes(self, lib, x, x_codes, y_ka=None, y_qbits=8):
+        """slfp_conv2d_fwd_codes: y_ka None -> float32 out, else the consumer's codes"""
+        L = lib.load()
+        io = lib.ConvIo(x_codes=1 if x_codes else 0, y_codes=0 if y_ka is None else 1,
+                        y_ka=float(np.float32(y_ka if y_ka is not None else 1.0)), y_qbits=y_qbits)
+        assert L.slfp_conv2d_codes_supported(ctypes.byref(self.d), ctypes.byref(io), 0, 1 if self.relu else 0) == 1, \
+            (self.kernel, self.s, x_codes, y_ka)
+        y = torch.empty(self.out_shape(), dtype=torch.float32 if y_ka is None else torch.uint8, device=x.device)
+        lib.check(L.slfp_conv2d_fwd_codes(ctypes.byref(self.d), ctypes.byref(io), x.data_ptr(), self.blob.data_ptr(), None,
+                                          self.scale.data_ptr() if self.scale is not None else None,
+                                          self.shift.data_ptr() if self.shift is not None else None,
+                                          1 if self.relu else 0, y.data_ptr(), _stream()))
+        return y
+
+
+def _synthetic_input(s, n, dev, gen, signed=False):
+    """post-ReLU-like activations spanning all binades and both clamps, with exact zeros (half of a ReLU's outputs)"""
+    x = torch.randn((n, s.h, s.w, s.c_in), generator=gen, device=dev)
+    if not signed:
+        x = torch.relu(x)
+    x = x * (6.0 * s.Ka)
+    x.view(-1)[::97] = 17.0 * s.Ka          # beyond the clamp
+    x.view(-1)[5::193] = 0.05 * s.Ka        # the "tiny" class
+    return x
+
+
+def test_code_tables_equal_long_form_for_all_2_32_inputs(lib, dev):
+    """Producer table (signed and unsigned variants) vs the long form behind slfp_encode_f32, decode tables vs
+    slfp_decode_f32: every float32 pattern, on the device."""
+    from cnns_slfp_quantization_amd import layer_specs
+    L = lib.load()
+    scales = [1.0, 0.171, 15.5 / 3.0, 2.0 ** -7, 0.4277248690205236, 1e-3, 37.25]
+    if SOAK:
+        scales += sorted({float(np.float32(s.Ka)) for net in layer_specs.nets() for s in layer_specs.conv_layers(net)})
+    out = torch.zeros(3, dtype=torch.int64, device=dev)
+    for fmt in (lib.FMT_ACT8, lib.FMT_SFP7):
+        for k in scales:
+            lib.check(L.slfp_debug_code_mismatches(float(np.float32(k)), fmt, out.data_ptr(), _stream()))
+            torch.cuda.synchronize()
+            assert out.tolist() == [0, 0, 0], (fmt, k, out.tolist())
+
+
+def _mobilenet_specs():
+    from cnns_slfp_quantization_amd import layer_specs
+    return layer_specs.conv_layers("mobilenetv1_imagenet224")
+
+
+def _distinct(specs):
+    seen, out = set(), []
+    for i, s in enumerate(specs):
+        key = (s.c_in, s.c_out, s.k, s.stride, s.h)
+        if key not in seen:
+            seen.add(key)
+            out.append(i)
+    return out
+
+
+@pytest.mark.parametrize("qbits", [8, 7])
+def test_each_mobilenet_layer_on_codes_is_bit_identical_to_the_float32_interface(lib, dev, qbits):
+    """All 19 distinct MobileNetV1-224 layer shapes (nets_imgnet/mobilenetv1.py:43-57), small batch, both formats:
+    consumer from codes == consumer from float32 (bit for bit); producer's bytes == slfp_encode_f32(float32 output)."""
+    specs = _mobilenet_specs()
+    gen = torch.Generator(device=dev).manual_seed(2024 + qbits)
+    fmt = lib.FMT_ACT8 if qbits == 8 else lib.FMT_SFP7
+    n = 3
+    for i in _distinct(specs):
+        s = specs[i]
+        ka_next = specs[i + 1].Ka if i + 1 < len(specs) else 0.2345
+        lay = _Layer(lib, s, n, qbits, dev, gen)
+        x = _synthetic_input(s, n, dev, gen, signed=(s.c_in == 3))
+        y_ref = lay.fwd_f32(lib, x)
+        codes_ref = _encode(lib, y_ref, ka_next, fmt)
+        if s.c_in == 3:
+            if qbits != 8:
+                continue   # the specialised stem kernel is SLFP<3,4> only; SFP<3,3> chains start after the stem
+            yc = lay.fwd_codes(lib, x, False, ka_next, qbits)
+            assert torch.equal(yc, codes_ref), ("stem", i)
+            continue
+        xc = _encode(lib, x, s.Ka, fmt)
+        y = lay.fwd_codes(lib, xc, True)                       # codes in, float32 out
+        assert torch.equal(y.view(torch.int32), y_ref.view(torch.int32)), (lay.kernel, i, "consumer", float((y - y_ref).abs().max()))
+        yc = lay.fwd_codes(lib, xc, True, ka_next, qbits)      # codes in, codes out
+        bad = int((yc != codes_ref).sum())
+        assert bad == 0, (lay.kernel, i, "producer", bad, yc.numel())
+
+
+def test_codes_without_relu_carry_the_sign(lib, dev):
+    """conv -> BN -> conv without a ReLU in between (ShuffleNetV2 branches): negative values keep their sign bit."""
+    specs = _mobilenet_specs()
+    gen = torch.Generator(device=dev).manual_seed(7)
+    for qbits, fmt in ((8, lib.FMT_ACT8), (7, lib.FMT_SFP7)):
+        for i in (5, 6, 13, 14):   # dw 128@56, pw 128->128@56, dw 512@14, pw 512->512@14
+            s = specs[i]
+            lay = _Layer(lib, s, 2, qbits, dev, gen, relu=False)
+            lay.shift -= 0.2
+            x = _synthetic_input(s, 2, dev, gen)
+            xc = _encode(lib, x, s.Ka, fmt)
+            y_ref = lay.fwd_f32(lib, x)
+            assert float((y_ref < 0).float().mean()) > 0.05
+            yc = lay.fwd_codes(lib, xc, True, specs[i + 1].Ka, qbits)
+            assert torch.equal(yc, _encode(lib, y_ref, specs[i + 1].Ka, fmt)), (qbits, i)
+
+
+def test_full_batch_chain_matches_the_float32_interface(lib, dev):
+    """BASELINE config 2 size: batch 256 through all 27 layers as ONE chain of codes (stem float32 -> codes ... -> last
+    pointwise codes -> float32), against the same layers on the float32 interface.  Images are independent, the chain is
+    bit-identical layer by layer, so the final float32 tensors must be EQUAL; intermediate code tensors are compared with
+    slfp_encode_f32 of the float32 chain's tensors."""
+    specs = _mobilenet_specs()
+    n = 256
+    gen = torch.Generator(device=dev).manual_seed(99)
+    layers = [_Layer(lib, s, n, 8, dev, gen) for s in specs]
+    for lay in layers:   # keep activations in range: BN scale so that outputs span the next layer's code range
+        lay.scale.mul_(1.0)
+    x = torch.randn((n, 224, 224, 3), generator=gen, device=dev) * (4.0 * specs[0].Ka)
+    # float32 interface
+    a = x
+    f32_codes_sample = {}
+    for i, lay in enumerate(layers):
+        a = lay.fwd_f32(lib, a)
+        if i + 1 < len(layers) and i in (0, 1, 2, 7, 12, 13, 24, 25):
+            f32_codes_sample[i] = _encode(lib, a, specs[i + 1].Ka, lib.FMT_ACT8)
+    y_ref = a
+    # code chain
+    c = layers[0].fwd_codes(lib, x, False, specs[1].Ka, 8)
+    for i in range(1, len(layers)):
+        if i - 1 in f32_codes_sample:
+            assert torch.equal(c, f32_codes_sample[i - 1]), ("codes after layer", i - 1)
+        last = i == len(layers) - 1
+        c = layers[i].fwd_codes(lib, c, True, None if last else specs[i + 1].Ka, 8)
+    assert torch.equal(c.view(torch.int32), y_ref.view(torch.int32))
+    assert float(y_ref.abs().max()) > 0 and bool(torch.isfinite(y_ref).all())
+
+
+def test_codes_vs_oracle_direct(lib, dev):
+    """One depthwise and one pointwise layer on codes against the CPU oracle itself (not only against the float32-interface
+    kernels): decode with the oracle, convolve in double, compare under the per-family bars of test_gpu_parity.py."""
+    specs = _mobilenet_specs()
+    gen = torch.Generator(device=dev).manual_seed(5)
+    for i, tol in ((7, 1e-5), (8, 1e-3)):   # dw 128@56 s2 (float32 FMA), pw 128->256@28 (single-pass fp16 MFMA)
+        s = specs[i]
+        lay = _Layer(lib, s, 2, 8, dev, gen, post=False, relu=False)
+        x = _synthetic_input(s, 2, dev, gen)
+        xc = _encode(lib, x, s.Ka, lib.FMT_ACT8)
+        y = lay.fwd_codes(lib, xc, True).cpu().numpy().transpose(0, 3, 1, 2)
+        xq = so.decode(xc.cpu().numpy(), so.FMT_ACT8 | so.FMT_EXT).transpose(0, 3, 1, 2)
+        assert np.array_equal(xq.view(np.uint32), so.quantize(x.cpu().numpy().transpose(0, 3, 1, 2), np.float32(s.Ka), so.FMT_ACT8).view(np.uint32))
+        ref = so.conv2d(np.ascontiguousarray(x.cpu().numpy().transpose(0, 3, 1, 2)), lay.w.cpu().numpy(), None, s.stride, s.pad, (1, 1),
+                        s.groups, np.float64(s.Ka), np.float64(s.Kw), 8)
+        d = np.abs(y.astype(np.float64) - ref)
+        assert d.max() <= tol * np.abs(ref).max(), (i, d.max(), np.abs(ref).max())
+
+
+def test_unsupported_combinations_are_refused(lib, dev):
+    L = lib.load()
+    specs = _mobilenet_specs()
+    d = _desc(lib, specs[2], 2, 8)
+    io = lib.ConvIo(x_codes=1, y_codes=1, y_ka=0.5, y_qbits=5)
+    assert L.slfp_conv2d_codes_supported(ctypes.byref(d), ctypes.byref(io), 0, 1) == 0       # bad consumer format
+    io = lib.ConvIo(x_codes=0, y_codes=1, y_ka=0.5, y_qbits=8)
+    assert L.slfp_conv2d_codes_supported(ctypes.byref(d), ctypes.byref(io), 0, 1) == 0       # float32 -> codes pointwise: not built
+    d3 = _desc(lib, specs[2], 2, 8)
+    d3.mfma_passes = lib.MFMA_F16X3
+    io = lib.ConvIo(x_codes=1, y_codes=0, y_ka=1.0, y_qbits=8)
+    assert L.slfp_conv2d_codes_supported(ctypes.byref(d3), ctypes.byref(io), 0, 1) == 0      # three-pass mode: not built
+    x = torch.zeros((2, 112, 112, 32), dtype=torch.uint8, device=dev)
+    y = torch.empty((2, 112, 112, 64), device=dev)
+    blob = torch.empty(L.slfp_conv2d_wprep_bytes(ctypes.byref(d3)), dtype=torch.uint8, device=dev)
+    rc = L.slfp_conv2d_fwd_codes(ctypes.byref(d3), ctypes.byref(io), x.data_ptr(), blob.data_ptr(), None, None, None, 1, y.data_ptr(), _stream())
+    assert rc == lib.ERR_UNSUPPORTED and "code-path" in lib.last_error()
