@@ -41,7 +41,8 @@ import torch.nn.functional as F
 
 from . import _lib
 from .sfp_quant import *  # noqa: F401,F403  (the reference re-exports these: conv2d_func.py:5)
-from .sfp_quant import _require_gpu_f32, _stream_handle, hip_quantize, weight_quantize_func, act_quantize_func
+from .sfp_quant import (_require_gpu_f32, _stream_handle, hip_quantize, hip_encode, hip_decode, weight_quantize_func,
+                        act_quantize_func)
 
 __all__ = ["torch", "nn", "F", "np", "conv2d_Q", "conv2d_Q_bias", "linear_Q", "options",
            "quantize_weight", "quantize_act", "quantize_layerout",
@@ -121,7 +122,7 @@ class _PreparedWeights:
 
 class _Plan:
     """What one (module, input shape, layout, scales, precision) combination resolves to in the C ABI."""
-    __slots__ = ("desc", "ho", "wo", "ws_bytes", "kernel")
+    __slots__ = ("desc", "ho", "wo", "ws_bytes", "kernel", "io", "codes_ok")
 
     def __init__(self, desc, ho, wo, ws_bytes, kernel):
         self.desc, self.ho, self.wo, self.ws_bytes, self.kernel = desc, ho, wo, ws_bytes, kernel
@@ -227,6 +228,88 @@ def _hip_conv2d(mod, x, weight, bias, cache_ok=False):
     return y.squeeze(0) if squeeze else y
 
 
+def _act_fmt(q_bit):
+    return _lib.FMT_ACT8 if q_bit == 8 else _lib.FMT_SFP7
+
+
+def _hip_conv2d_codes(mod, x, weight, bias):
+    """Conv2d_Q.forward inside a chain linked by fusion.link_codes: `x` is float32 or the uint8 codes the previous layer
+    wrote for THIS module's Ka / q_bit; the result is uint8 codes for the next layer (mod._code_out = (Ka_next, q_bit_next))
+    or float32.  One slfp_conv2d_fwd_codes call where libslfp_hip has a kernel for the combination; otherwise the same
+    values through the float32 interface plus slfp_encode_f32 / slfp_decode_f32 (always correct, never faster)."""
+    x_codes = x.dtype == torch.uint8
+    out = mod._code_out
+    if not x_codes:
+        _require_gpu_f32(x, "Conv2d_Q")
+    elif not x.is_cuda:
+        raise RuntimeError("Conv2d_Q: code tensors live on the ROCm device")
+    if x.dim() != 4 or not x.is_contiguous(memory_format=torch.channels_last):
+        # the code path is NHWC only; anything else takes the float32 interface
+        x32 = hip_decode(x, _act_fmt(mod.q_bit)) if x_codes else x
+        y = _hip_conv2d(mod, x32, weight, bias, cache_ok=True)
+        return hip_encode(y, out[0], _act_fmt(out[1])) if out is not None else y
+    L = _lib.load()
+    N, C, H, W = x.shape
+    if C != mod.in_channels:
+        raise RuntimeError(f"Given groups={mod.groups}, weight of size {list(weight.shape)}, expected input"
+                           f"{list(x.shape)} to have {mod.in_channels} channels, but got {C} channels instead")
+    ka, kw_ = _scale_key(mod.Ka, "Ka"), _scale_key(mod.Kw, "Kw")
+    pkey = ("codes", N, H, W, x_codes, out, ka, kw_, options.mfma_passes, mod.stride, mod.padding, mod.dilation, tuple(weight.shape))
+    plan = mod._plans.get(pkey)
+    if plan is None:
+        sh, sw = _pair(mod.stride)
+        ph, pw = _pair(mod.padding)
+        dh, dw = _pair(mod.dilation)
+        d = _lib.ConvDesc(n=N, c_in=C, h=H, w=W, c_out=mod.out_channels, kh=weight.shape[2], kw=weight.shape[3],
+                          stride_h=sh, stride_w=sw, pad_h=ph, pad_w=pw, dil_h=dh, dil_w=dw, groups=mod.groups,
+                          x_layout=_lib.LAYOUT_NHWC, y_layout=_lib.LAYOUT_NHWC, qbits=mod.q_bit,
+                          ka=_f32(_scalar_scale(mod.Ka, "Ka")), kw_scale=_f32(_scalar_scale(mod.Kw, "Kw")),
+                          mfma_passes=options.mfma_passes, reserved=0)
+        ho, wo = ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(L.slfp_conv2d_out_shape(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)))
+        io = _lib.ConvIo(x_codes=1 if x_codes else 0, y_codes=1 if out is not None else 0,
+                         y_ka=_f32(out[0]) if out is not None else 1.0, y_qbits=int(out[1]) if out is not None else 8)
+        post = mod._post
+        flags = int(post[2]) if post is not None else 0
+        ok = bool(L.slfp_conv2d_codes_supported(ctypes.byref(d), ctypes.byref(io), 1 if bias is not None else 0, flags))
+        plan = _Plan(d, ho.value, wo.value, 0, L.slfp_conv2d_kernel_name(ctypes.byref(d)).decode())
+        plan.io, plan.codes_ok = io, ok
+        if len(mod._plans) >= 64:
+            mod._plans.clear()
+        mod._plans[pkey] = plan
+    if not plan.codes_ok:
+        x32 = hip_decode(x, _act_fmt(mod.q_bit)) if x_codes else x
+        y = _hip_conv2d(mod, x32, weight, bias, cache_ok=True)
+        return hip_encode(y, out[0], _act_fmt(out[1])) if out is not None else y
+    d = plan.desc
+    with _on_device(x.device):
+        blob = mod._prep.get(L, d, weight, want_weight_q=False, cache=True, kernel=plan.kernel)
+        y = torch.empty((N, mod.out_channels, plan.ho, plan.wo), dtype=torch.uint8 if out is not None else torch.float32,
+                        device=x.device, memory_format=torch.channels_last)
+        b = None
+        if bias is not None:
+            b = bias.detach()
+            b = b if b.is_contiguous() else b.contiguous()
+        ps = psh = None
+        relu = 0
+        if mod._post is not None:
+            ps, psh, relu = mod._post
+            if ps is not None and ps.device != x.device:
+                ps, psh = ps.to(x.device), psh.to(x.device)
+                mod._post = (ps, psh, relu)
+        _lib.check(L.slfp_conv2d_fwd_codes(ctypes.byref(d), ctypes.byref(plan.io), x.data_ptr(), blob.data_ptr(),
+                                           b.data_ptr() if b is not None else None,
+                                           ps.data_ptr() if ps is not None else None,
+                                           psh.data_ptr() if psh is not None else None, int(relu), y.data_ptr(), _stream_handle(x)))
+    mod._last_kernel = plan.kernel + ("+codes_in" if x_codes else "") + ("+codes_out" if out is not None else "")
+    if x_codes:
+        mod._last_input, mod._last_codes = None, x.detach()
+    else:
+        mod._last_input, mod._last_codes = x.detach(), None
+    mod._input_q = None
+    return y
+
+
 class _SlfpConv2dFn(torch.autograd.Function):
     """HIP forward; backward = the reference's composite (STE through both quantizers:
     utils/sfp_quant.py:50-53, :99-102; conv gradients from torch.nn.grad on the GPU)."""
@@ -289,6 +372,8 @@ def _conv_class(q_bit, Kw, Ka, bias_default, scaled_bias):
             self._weight_q32 = None
             self._last_kernel = None
             self._post = None  # (scale, shift, relu): fused eval-BN + ReLU epilogue (fusion.fuse_bn_relu)
+            self._code_out = None   # (Ka, q_bit) of the next Conv2d_Q: hand it 1-byte codes (fusion.link_codes)
+            self._last_codes = None
             self._scaled_bias = scaled_bias
             self.output = None
 
@@ -301,13 +386,16 @@ def _conv_class(q_bit, Kw, Ka, bias_default, scaled_bias):
             if self._input_q is None and self._last_input is not None:
                 fmt = _lib.FMT_ACT8 if self.q_bit == 8 else _lib.FMT_SFP7
                 self._input_q = hip_quantize(self._last_input, _f32(self.Ka), fmt)
+            elif self._input_q is None and self._last_codes is not None:
+                # inside a code chain the input arrived already quantized: input_q = decode(codes), bit for bit
+                self._input_q = hip_decode(self._last_codes, _act_fmt(self.q_bit))
             return self._input_q
 
         @property
         def weight_q(self):
             if self.q_bit == 32:
                 return self._weight_q32
-            if self._last_input is None:
+            if self._last_input is None and self._last_codes is None:
                 return None
             stale = self._prep.weight_q is None or self._prep.key is None or self._prep.key[2] != self.weight._version
             if stale or self.training or torch.is_grad_enabled():   # p.data updates are invisible to _version
@@ -339,6 +427,14 @@ def _conv_class(q_bit, Kw, Ka, bias_default, scaled_bias):
                 return self.output
             if self.q_bit not in (8, 7):
                 raise UnboundLocalError("q_bit must be 32, 8 or 7 (utils/sfp_quant.py:142-147)")
+            if input.dtype == torch.uint8 or self._code_out is not None:
+                # a link of fusion.link_codes: 1-byte codes on one or both sides (inference only)
+                if self.training or self._scaled_bias is False and self.bias is not None:
+                    raise RuntimeError("Conv2d_Q: code links (fusion.link_codes) are inference-only and need the scaled bias class; "
+                                       "call fusion.unlink_codes(model)")
+                with torch.no_grad():
+                    self.output = _hip_conv2d_codes(self, input, self.weight, self.bias)
+                return self.output
             need_grad = torch.is_grad_enabled() and (input.requires_grad or self.weight.requires_grad or
                                                      (self.bias is not None and self.bias.requires_grad))
             if self._post is not None and (need_grad and self.training):

@@ -388,8 +388,11 @@ __global__ __launch_bounds__(256) void k_stem_fixed(const float* __restrict__ x,
                 r.y = ((acc[q].y + bq.y) * p.s1) * p.s2;
                 r.z = ((acc[q].z + bq.z) * p.s1) * p.s2;
                 r.w = ((acc[q].w + bq.w) * p.s1) * p.s2;
-                r = post_apply_v(r, p.post, pv);
-                uint32_t code = enc4_code<false>(r, p.enc_out.r1, p.enc_out.lo, p.enc_out.hi, senc);
+                PostOp po = p.post;
+                po.relu = 0;   // with code output the ReLU is the quantizer's (enc4_code_relu)
+                r = post_apply_v(r, po, pv);
+                uint32_t code = p.sgn ? enc4_code<false>(r, p.enc_out.r1, p.enc_out.lo, p.enc_out.hi, senc)
+                                      : enc4_code_relu(r, p.enc_out.r1, p.enc_out.lo, p.enc_out.hi, senc);
                 if (p.sgn) {
                     const float rs[4] = {r.x, r.y, r.z, r.w};
                     uint32_t out = 0;

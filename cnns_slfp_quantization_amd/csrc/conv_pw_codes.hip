@@ -163,7 +163,9 @@ __global__ __launch_bounds__(kPwcThreads) void k_pwc_stream(const PwcParams p) {
             } else {
                 r = epilogue(acc, make_float4(0.f, 0.f, 0.f, 0.f), p.s1x, p.s2);
             }
-            if (p.post.relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+            if constexpr (!YC) {   // with code output the ReLU is the quantizer's (enc4_code_relu)
+                if (p.post.relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+            }
             return r;
         };
         if constexpr (YC) {
@@ -173,8 +175,8 @@ __global__ __launch_bounds__(kPwcThreads) void k_pwc_stream(const PwcParams p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float4 r = tile_out(j0 + j);
-                    c[j] = enc4_code<false>(r, r1, lo, hi, senc);
-                    if (p.sgn) c[j] = code_sign4(c[j], r, p.fmt_out);
+                    if (p.sgn) c[j] = code_sign4(enc4_code<false>(r, r1, lo, hi, senc), r, p.fmt_out);
+                    else c[j] = enc4_code_relu(r, r1, lo, hi, senc);
                 }
                 rows_transpose4(c[0], c[1], c[2], c[3]);   // lane-quarter kq now holds channels 16 (j0 + kq) + 0..15
                 const int n = (j0 + kq) * 16;
@@ -322,7 +324,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 4) void k_pwc_ti
             r.x = __builtin_fmaf(r.x, sc.x, sh.x); r.y = __builtin_fmaf(r.y, sc.y, sh.y);
             r.z = __builtin_fmaf(r.z, sc.z, sh.z); r.w = __builtin_fmaf(r.w, sc.w, sh.w);
         }
-        if (p.post.relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+        if constexpr (!YC) {
+            if (p.post.relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+        }
         return r;
     };
     if constexpr (YC) {
@@ -334,8 +338,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 4) void k_pwc_ti
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const float4 r = out_tile(i, j);
-                c[j] = enc4_code<false>(r, r1, lo, hi, senc);
-                if (p.sgn) c[j] = code_sign4(c[j], r, p.fmt_out);
+                if (p.sgn) c[j] = code_sign4(enc4_code<false>(r, r1, lo, hi, senc), r, p.fmt_out);
+                else c[j] = enc4_code_relu(r, r1, lo, hi, senc);
             }
             rows_transpose4(c[0], c[1], c[2], c[3]);   // lane-quarter kq: channels 16 (ntile0 + kq) + 0..15 of pixel row `col`
             const int row = (wm * MT + i) * 16 + col;

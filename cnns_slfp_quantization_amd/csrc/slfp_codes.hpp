@@ -147,6 +147,44 @@ __device__ __forceinline__ uint32_t enc4_code(const float4 x, const float r1, co
     return d;
 }
 
+// The same for a producer whose epilogue ends in a ReLU, with the ReLU folded into the quantizer: the bin estimate and the
+// compare use x itself instead of |x|, so a negative x (and -0) clamps into the lowest bin and fails its compare = the
+// class of exact zero (0x01) -- exactly the code of max(x, 0).  No v_max, and the two multiplies of a pair are one v_pk_mul.
+__device__ __forceinline__ uint32_t enc4_code_relu(const float4 x, const float r1, const float lo, const float hi,
+                                                   const unsigned char* __restrict__ sTab) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 p01 = f32x2{x.x, x.y} * r1, p23 = f32x2{x.z, x.w} * r1;   // v_pk_mul_f32: the same IEEE products
+    const float q0 = __builtin_amdgcn_fmed3f(p01[0], lo, hi);
+    const float q1 = __builtin_amdgcn_fmed3f(p01[1], lo, hi);
+    const float q2 = __builtin_amdgcn_fmed3f(p23[0], lo, hi);
+    const float q3 = __builtin_amdgcn_fmed3f(p23[1], lo, hi);
+    const uint2 e0 = *reinterpret_cast<const uint2*>(sTab + enc_bin_off(q0));
+    const uint2 e1 = *reinterpret_cast<const uint2*>(sTab + enc_bin_off(q1));
+    const uint2 e2 = *reinterpret_cast<const uint2*>(sTab + enc_bin_off(q2));
+    const uint2 e3 = *reinterpret_cast<const uint2*>(sTab + enc_bin_off(q3));
+    uint32_t d;
+    asm("v_cmp_ge_f32_e64 vcc, %1, %2\n\t"
+        "v_cndmask_b32_sdwa %0, %3, %3, vcc dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1\n\t"
+        "v_cmp_ge_f32_e64 vcc, %4, %5\n\t"
+        "v_cndmask_b32_sdwa %0, %6, %6, vcc dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:BYTE_1\n\t"
+        "v_cmp_ge_f32_e64 vcc, %7, %8\n\t"
+        "v_cndmask_b32_sdwa %0, %9, %9, vcc dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:BYTE_1\n\t"
+        "v_cmp_ge_f32_e64 vcc, %10, %11\n\t"
+        "v_cndmask_b32_sdwa %0, %12, %12, vcc dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:BYTE_1\n\t"
+        "s_nop 0"
+        : "=&v"(d)
+        : "v"(x.x), "v"(e0.x), "v"(e0.y), "v"(x.y), "v"(e1.x), "v"(e1.y), "v"(x.z), "v"(e2.x), "v"(e2.y),
+          "v"(x.w), "v"(e3.x), "v"(e3.y)
+        : "vcc");
+    if (__builtin_expect(enc_has_nan4(x), 0)) {
+        if (x.x != x.x) d &= 0xFFFFFF00u;
+        if (x.y != x.y) d &= 0xFFFF00FFu;
+        if (x.z != x.z) d &= 0xFF00FFFFu;
+        if (x.w != x.w) d &= 0x00FFFFFFu;
+    }
+    return d;
+}
+
 // SFP<3,3> codes carry the sign in bit 6: enc4_code<true> puts it in bit 7; move it.
 template <int FMT, bool SIGNED>
 __device__ __forceinline__ uint32_t enc4_code_fmt(const float4 x, const float r1, const float lo, const float hi,

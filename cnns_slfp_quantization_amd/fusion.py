@@ -289,3 +289,95 @@ def unfuse_dw_pw(model):
                 seq._modules[name] = blk.pw
                 n += 1
     return n
+
+
+# ------------------------------------------------------------------ 1-byte activation codes between layers
+def link_codes(model, example_input=None):
+    """After fuse_bn_relu: wherever a Conv2d_Q's (fused BN + ReLU) output feeds the next Conv2d_Q of an nn.Sequential
+    directly (only nn.Identity in between -- nets_imgnet/mobilenetv1.py:24-33 after fusion), link the two: the producer's
+    epilogue applies the CONSUMER's quantize_act(. / Ka) (utils/conv2d_func.py:21) and stores 1-byte codes, the consumer
+    decodes them (libslfp_hip: slfp_conv2d_fwd_codes).  Same classes, same values: the net's output is bit-identical to
+    the unlinked fused net (single-pass MFMA mode / SFP<3,3>), activations cross HBM as 1 B per element instead of 4.
+    With `example_input` (a channels_last ROCm batch) only links for which both kernels exist are made (one forward
+    records the shapes); without it every candidate is linked and combinations without a kernel run through the float32
+    interface plus an encode / decode pass (correct, slower).  Inference only.  Returns the number of links."""
+    from . import _lib
+    from .conv2d_func import _f32, _scalar_scale, options
+    shapes = {}
+    if example_input is not None:
+        hooks = []
+        for m in model.modules():
+            if _is_conv_q(m):
+                hooks.append(m.register_forward_pre_hook(lambda mod, inp: shapes.__setitem__(mod, tuple(inp[0].shape))))
+        was = [(m, m._code_out) for m in model.modules() if _is_conv_q(m)]
+        try:
+            with torch.no_grad():
+                model(example_input)
+        finally:
+            for h in hooks:
+                h.remove()
+
+    def supported(m, x_codes, out):
+        if example_input is None:
+            return True
+        shp = shapes.get(m)
+        if shp is None or len(shp) != 4:
+            return False
+        L = _lib.load()
+        n, c, h, w = shp
+        d = _lib.ConvDesc(n=n, c_in=c, h=h, w=w, c_out=m.out_channels, kh=m.weight.shape[2], kw=m.weight.shape[3],
+                          stride_h=m.stride[0], stride_w=m.stride[1], pad_h=m.padding[0], pad_w=m.padding[1], dil_h=m.dilation[0],
+                          dil_w=m.dilation[1], groups=m.groups, x_layout=_lib.LAYOUT_NHWC, y_layout=_lib.LAYOUT_NHWC, qbits=m.q_bit,
+                          ka=_f32(_scalar_scale(m.Ka, "Ka")), kw_scale=_f32(_scalar_scale(m.Kw, "Kw")),
+                          mfma_passes=options.mfma_passes, reserved=0)
+        io = _lib.ConvIo(x_codes=1 if x_codes else 0, y_codes=1 if out is not None else 0,
+                         y_ka=_f32(out[0]) if out is not None else 1.0, y_qbits=int(out[1]) if out is not None else 8)
+        flags = int(m._post[2]) if m._post is not None else 0
+        return bool(L.slfp_conv2d_codes_supported(ctypes.byref(d), ctypes.byref(io), 1 if m.bias is not None else 0, flags))
+
+    def eligible(m):
+        return (_is_conv_q(m) and m.q_bit in (8, 7) and not m.training and isinstance(m.padding, tuple)
+                and (m.bias is None or getattr(m, "_scaled_bias", False)) and not (m._post is not None and (int(m._post[2]) & 2)))
+
+    def flat(seq):   # an nn.Sequential of nn.Sequentials runs its leaves in order (conv_bn / conv_dw blocks of the reference nets)
+        for m in seq._modules.values():
+            if isinstance(m, nn.Sequential):
+                yield from flat(m)
+            else:
+                yield m
+
+    nested = {c for m in model.modules() if isinstance(m, nn.Sequential) for c in m._modules.values() if isinstance(c, nn.Sequential)}
+    n_links = 0
+    for seq in [m for m in model.modules() if isinstance(m, nn.Sequential) and m not in nested]:
+        mods = [m for m in flat(seq) if not isinstance(m, nn.Identity)]
+        # candidate links: consecutive eligible convs
+        cand = [i for i in range(len(mods) - 1) if eligible(mods[i]) and eligible(mods[i + 1])]
+        # a conv can consume codes only if its producer link exists; walk left to right and keep links whose two sides have kernels
+        linked_in = set()
+        for i in cand:
+            a, b = mods[i], mods[i + 1]
+            out = (float(_scalar_scale(b.Ka, "Ka")), int(b.q_bit))
+            a_in = i in linked_in                       # does `a` itself read codes?
+            if not supported(a, a_in, out):
+                # head of a run without a float32 -> codes kernel: enter the chain through one slfp_encode_f32 pass if at least
+                # two more layers then run on codes
+                if a_in or not (i + 1 in cand and supported(b, True, (float(_scalar_scale(mods[i + 2].Ka, "Ka")), int(mods[i + 2].q_bit)))):
+                    continue
+            # b with codes in: it may or may not write codes itself; require the float32-out form here (the code-out form is
+            # checked when its own link is made; if that fails b keeps float32 out)
+            if not supported(b, True, None):
+                continue
+            a._code_out = out
+            linked_in.add(i + 1)
+            n_links += 1
+    return n_links
+
+
+def unlink_codes(model):
+    """Undo link_codes."""
+    n = 0
+    for m in model.modules():
+        if _is_conv_q(m) and m._code_out is not None:
+            m._code_out = None
+            n += 1
+    return n

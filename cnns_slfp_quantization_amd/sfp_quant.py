@@ -55,6 +55,33 @@ def hip_quantize(x, scale_div, fmt):
     return y
 
 
+def hip_encode(x, scale_div, fmt):
+    """uint8 extended codes of Q_fmt(x / float32(scale_div)) (slfp_encode_f32 with SLFP_FMT_EXT), same layout as x:
+    decode(code) == quantize(x) bit for bit.  The 1-byte inter-layer format of fusion.link_codes."""
+    _require_gpu_f32(x, "slfp encode")
+    L = _lib.load()
+    dense = x.is_contiguous() or (x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last))
+    src = x if dense else x.contiguous()
+    c = torch.empty_like(src, dtype=torch.uint8)
+    with torch.cuda.device(x.device):
+        _lib.check(L.slfp_encode_f32(src.data_ptr(), c.data_ptr(), src.numel(), float(np.float32(scale_div)), fmt | _lib.FMT_EXT,
+                                     _stream_handle(x)))
+    return c
+
+
+def hip_decode(codes, fmt):
+    """float32 values of extended codes (slfp_decode_f32 with SLFP_FMT_EXT), same layout as `codes`."""
+    if not codes.is_cuda or codes.dtype != torch.uint8:
+        raise TypeError("slfp decode: expected a ROCm ('cuda') uint8 tensor of codes")
+    L = _lib.load()
+    dense = codes.is_contiguous() or (codes.dim() == 4 and codes.is_contiguous(memory_format=torch.channels_last))
+    src = codes if dense else codes.contiguous()
+    y = torch.empty_like(src, dtype=torch.float32)
+    with torch.cuda.device(codes.device):
+        _lib.check(L.slfp_decode_f32(src.data_ptr(), y.data_ptr(), src.numel(), fmt | _lib.FMT_EXT, _stream_handle(codes)))
+    return y
+
+
 def _make_qfn(fmt):
     class qfn(torch.autograd.Function):
         @staticmethod

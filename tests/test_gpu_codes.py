@@ -254,3 +254,72 @@ def test_unsupported_combinations_are_refused(lib, dev):
     blob = torch.empty(L.slfp_conv2d_wprep_bytes(ctypes.byref(d3)), dtype=torch.uint8, device=dev)
     rc = L.slfp_conv2d_fwd_codes(ctypes.byref(d3), ctypes.byref(io), x.data_ptr(), blob.data_ptr(), None, None, None, 1, y.data_ptr(), _stream())
     assert rc == lib.ERR_UNSUPPORTED and "code-path" in lib.last_error()
+
+
+# ------------------------------------------------------------------ host side: fusion.link_codes on the drop-in modules
+def _mobilenet224(dev, qbits=8, batch=6):
+    """nets_imgnet/mobilenetv1.py:24-61 from the drop-in modules with the parameters and BatchNorm statistics of the
+    committed config-2 fixture (tests/golden/net224_golden.npz: generated by the imported reference)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import netgen
+    import utils.conv2d_func as cf
+    from cnns_slfp_quantization_amd import layer_specs
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "net224_golden.npz"))
+    rows = [r for r in layer_specs.nets()["mobilenetv1_imagenet224"]["layers"] if r["kind"] == "conv"]
+    scales = [(r["Ka"], r["Kw"]) for r in rows]
+    net = netgen.load_bn_stats_(netgen.fill_parameters(netgen.build_mobilenetv1_imagenet(cf.conv2d_Q, qbits, scales)), gold)
+    net = net.to(dev).eval().to(memory_format=torch.channels_last)
+    x = netgen.net_input224(64)[:batch].to(dev).contiguous(memory_format=torch.channels_last)
+    return net, x, gold
+
+
+@pytest.mark.parametrize("qbits", [8, 7])
+def test_link_codes_whole_net_is_bit_identical_to_the_fused_net(dev, qbits):
+    """nets_imgnet/mobilenetv1.py:43-61 built from the drop-in modules: fuse_bn_relu, then link_codes.  All 26 hand-overs
+    between the 27 convs become 1-byte codes (the SFP<3,3> stem has no code-output kernel: its link runs the float32 kernel
+    plus one slfp_encode_f32 pass) and the logits do not change by a single bit; input_q read back inside the chain equals
+    the fused net's."""
+    from cnns_slfp_quantization_amd import fusion
+    net, x, gold = _mobilenet224(dev, qbits, 16)
+    with torch.no_grad():
+        assert fusion.fuse_bn_relu(net) == 27
+        y_fused = net(x)
+        conv5 = net.model[3][0]
+        xq_fused = conv5.input_q.clone()
+        n = fusion.link_codes(net, example_input=x)
+        assert n == 26, n
+        y_codes = net(x)
+        assert y_codes.dtype == torch.float32
+        assert torch.equal(y_codes.view(torch.int32), y_fused.view(torch.int32))
+        if qbits == 8:   # the reference's own logits for these images (config-2 fixture), same bars as the float32 interface
+            G = gold["logits_q8"][:16]
+            Lg = y_codes.cpu().numpy()
+            d = np.abs(Lg.astype(np.float64) - G)
+            assert d.max() <= 5e-2 * np.abs(G).max() and np.linalg.norm(d) <= 4e-2 * np.linalg.norm(G)
+            assert float((Lg.argmax(1) == G.argmax(1)).mean()) >= 0.95
+        assert "codes_in" in conv5._last_kernel and "codes_out" in conv5._last_kernel
+        assert torch.equal(conv5.input_q.view(torch.int32), xq_fused.view(torch.int32))   # decode(codes) == QA(x / Ka)
+        # optimistic linking (no example input) gives the same links and the same bits
+        assert fusion.unlink_codes(net) == n
+        assert fusion.link_codes(net) >= n
+        assert torch.equal(net(x).view(torch.int32), y_fused.view(torch.int32))
+        assert fusion.unlink_codes(net) > 0
+        assert torch.equal(net(x).view(torch.int32), y_fused.view(torch.int32))
+        # as one hipGraph
+        fusion.link_codes(net, example_input=x)
+        from cnns_slfp_quantization_amd.graph import GraphedModule
+        g = GraphedModule(net)
+        assert torch.equal(g(x).view(torch.int32), y_fused.view(torch.int32))
+        assert torch.equal(g(x).view(torch.int32), y_fused.view(torch.int32))
+
+
+def test_linked_modules_refuse_training(dev):
+    from cnns_slfp_quantization_amd import fusion
+    net, x, _ = _mobilenet224(dev, 8)
+    with torch.no_grad():
+        fusion.fuse_bn_relu(net)
+        fusion.link_codes(net)
+    net.train()
+    with pytest.raises(RuntimeError, match="inference-only"):
+        net.model[1][0](torch.zeros((1, 32, 8, 8), device=dev))
