@@ -176,7 +176,7 @@ def whole_net(specs, net, batch, dev, steps):
     x = torch.randn((batch, 3, 224, 224), device=dev, generator=g).contiguous(memory_format=torch.channels_last)
     out = {}
     with torch.no_grad():
-        for tag in ("stock_bn_relu", "fused_bn_relu", "fused_dw_pw"):
+        for tag in ("stock_bn_relu", "fused_bn_relu", "fused_dw_pw"):   # then "fused_codes" below
             if tag == "fused_bn_relu":
                 fusion.fuse_bn_relu(model)
             if tag == "fused_dw_pw":   # MobileNet blocks as ONE kernel each where libslfp_hip supports the pair (csrc/conv_dwpw.hip)
@@ -201,12 +201,28 @@ def whole_net(specs, net, batch, dev, steps):
             model(x)
         torch.cuda.synchronize()
         out["fused_bn_relu"] = max(out["fused_bn_relu"], round(batch * steps / (time.perf_counter() - t0), 1))
-        fusion.fuse_dw_pw(model)
-        if out["fused_dw_pw"] < out["fused_bn_relu"]:   # replay the faster of the two nets below
-            fusion.unfuse_dw_pw(model)
-            out["hipgraph_net"] = "fused_bn_relu"
-        else:
-            out["hipgraph_net"] = "fused_dw_pw"
+        # the fused net with every conv -> conv hand-over as 1-byte SLFP codes (fusion.link_codes; bit-identical logits)
+        try:
+            y_fused = model(x)
+            out["code_links"] = fusion.link_codes(model, example_input=x)
+            for _ in range(2):
+                y_codes = model(x)
+            out["fused_codes_matches_fused"] = bool(torch.equal(y_codes, y_fused))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                model(x)
+            torch.cuda.synchronize()
+            out["fused_codes"] = round(batch * steps / (time.perf_counter() - t0), 1)
+        except Exception as e:  # secondary number
+            out["fused_codes"] = None
+            out["fused_codes_error"] = str(e)[:200]
+        best = max((out.get("fused_codes") or 0, "fused_codes"), (out["fused_bn_relu"], "fused_bn_relu"), (out["fused_dw_pw"], "fused_dw_pw"))[1]
+        if best != "fused_codes":
+            fusion.unlink_codes(model)
+        if best == "fused_dw_pw":
+            fusion.fuse_dw_pw(model)
+        out["hipgraph_net"] = best
         # the fused net replayed as ONE hipGraph (all launches go to the capture stream through the C ABI):
         # removes the per-layer Python/launch latency and the inter-kernel gaps
         try:
@@ -444,6 +460,90 @@ def run_config(L, net, batch, qbits, passes, steps, warmup, dev, rank, world, po
     return res, rank_dts
 
 
+def run_codes_config(L, net, batch, qbits, steps, warmup, dev):
+    """The same 27 layers as ONE chain of 1-byte activation codes (second half; slfp_conv2d_fwd_codes):
+    every layer with the fused BatchNorm + ReLU epilogue, the stem reading float32 images and writing the next layer's
+    codes, every other layer reading codes (of its own synthetic input, resident in HBM) and writing codes, the last one
+    writing float32.  Algorithmic bytes: 1 B per activation element on a code side, 4 B on a float32 side, weights once
+    per batch.  Bit-identical to the float32 interface (tests/test_gpu_codes.py); single-pass MFMA mode."""
+    specs = layer_specs.conv_layers(net)
+    gen = torch.Generator(device=dev).manual_seed(4321)
+    stream = torch.cuda.current_stream().cuda_stream
+    fmt = (_lib.FMT_ACT8 if qbits == 8 else _lib.FMT_SFP7) | _lib.FMT_EXT
+    layers = []
+    for i, s in enumerate(specs):
+        l = Layer(L, s, batch, dev, _lib.MFMA_F16X1, gen, qbits, post=True)
+        l.prepare(L, stream)
+        last = i == len(specs) - 1
+        first = s.c_in == 3
+        l.io = _lib.ConvIo(x_codes=0 if first else 1, y_codes=0 if last else 1,
+                           y_ka=float(np.float32(specs[i + 1].Ka if not last else 1.0)), y_qbits=qbits)
+        l.codes_ok = bool(L.slfp_conv2d_codes_supported(ctypes.byref(l.desc), ctypes.byref(l.io), 0, 1))
+        if not l.codes_ok:
+            return None
+        if not first:
+            xc = torch.empty(l.x.shape, dtype=torch.uint8, device=dev)
+            _lib.check(L.slfp_encode_f32(l.x.data_ptr(), xc.data_ptr(), l.x.numel(), float(l.desc.ka), fmt, stream))
+            l.x = xc
+        if not last:
+            l.y = torch.empty(l.y.shape, dtype=torch.uint8, device=dev)
+        l.cbytes = batch * (s.in_elems * (4 if first else 1) + s.out_elems * (4 if last else 1)) + 4 * s.w_elems
+        l.family = ("stem" if first else ("dw3x3" if s.groups > 1 else "pw_mfma")) + "_codes"
+        layers.append(l)
+    torch.cuda.synchronize()
+
+    def run(l):
+        rc = L.slfp_conv2d_fwd_codes(ctypes.byref(l.desc), ctypes.byref(l.io), l.x.data_ptr(), l.blob.data_ptr(), None,
+                                     l.post[0].data_ptr(), l.post[1].data_ptr(), 1, l.y.data_ptr(), stream)
+        if rc != 0:
+            _lib.check(rc)
+
+    def step():
+        for l in layers:
+            run(l)
+
+    for _ in range(warmup):
+        step()
+    dt = timed_steps(step, steps, 1, dev)
+    ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in layers] for _ in range(steps)]
+    for k in range(steps):
+        for i, l in enumerate(layers):
+            ev[k][i][0].record()
+            run(l)
+            ev[k][i][1].record()
+    torch.cuda.synchronize()
+    layer_ms = [float(np.mean([ev[k][i][0].elapsed_time(ev[k][i][1]) for k in range(steps)])) for i in range(len(layers))]
+    fam = {}
+    for l, ms in zip(layers, layer_ms):
+        f = fam.setdefault(l.family, {"ms": 0.0, "bytes": 0, "launches": 0})
+        f["ms"] += ms
+        f["bytes"] += l.cbytes
+        f["launches"] += 1
+    dominant = max(fam, key=lambda k: fam[k]["ms"])
+    dom = fam[dominant]
+    dom_gbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+    value = batch * steps / dt
+    bytes_img = sum(l.cbytes for l in layers) / batch
+    f32_bytes_img = layer_specs.algorithmic_bytes_per_image(net, batch)
+    res = {"value": round(value, 1), "unit": "images/sec", "ms_per_step": round(dt / steps * 1e3, 4),
+           "algorithmic_bytes_per_image": int(bytes_img),
+           "hbm_roofline_frac_whole_path": round(bytes_img * value / 1e9 / HBM_PEAK_GBS, 4),
+           "float32_interface_bytes_equivalent_frac": round(f32_bytes_img * value / 1e9 / HBM_PEAK_GBS, 4),
+           "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(dom_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(dom_gbs / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dominant, net + "+codes", batch)[0],
+                        "launches_per_step": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
+                        "algorithmic_bytes_per_launch": int(dom["bytes"] / dom["launches"])},
+           "kernels": {k: {"ms_per_step": round(v["ms"], 4), "GB/s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1), "launches": v["launches"]}
+                       for k, v in fam.items()},
+           "note": "every layer with the fused BN + ReLU epilogue; activations between layers as 1-byte SLFP codes (1 B/elem "
+                   "algorithmic); bit-identical to the float32 interface; these kernels are VALU-issue-bound, not HBM-bound "
+                   "(profiles/r03c*): `float32_interface_bytes_equivalent_frac` prices the same images/s with the float32 "
+                   "interface's bytes"}
+    del layers
+    torch.cuda.empty_cache()
+    return res
+
+
 def codec_bench(L, dev, n=1 << 28, reps=5):
     """the standalone codec as a bandwidth kernel -- slfp_quantize_f32 (4 B in + 4 B out per
     element) and slfp_encode_f32 (4 B in + 1 B out) on 1 GiB of float32, HIP events on the launch stream."""
@@ -558,6 +658,13 @@ def main():
                     other[net] = {"batch": b, "qbits": q, "error": str(e)[:200]}
             out["other_configs"] = other
             out["codec"] = codec_bench(L, dev)
+        if args.net == "mobilenetv1_imagenet224" and args.passes in (0, 1) and not args.post:
+            try:   # secondary measurement: the same layers chained through 1-byte codes
+                cp = run_codes_config(L, args.net, batch, args.qbits, args.steps, args.warmup, dev)
+                if cp:
+                    out["codes_path"] = cp
+            except Exception as e:
+                out["codes_path"] = {"error": str(e)[:200]}
         if not args.no_whole_net:
             wn = whole_net(layer_specs.conv_layers(args.net), args.net, batch, dev, max(3, args.steps // 2))
             if wn:
