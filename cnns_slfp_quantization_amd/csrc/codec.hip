@@ -57,6 +57,24 @@ int raise_lds_limit(const void* fn, size_t lds_bytes) {
     return SLFP_OK;
 }
 
+static Switches read_switches() {
+    Switches w;
+    w.long_encode = std::getenv("SLFP_LONG_ENCODE") != nullptr;
+    w.dw_old = std::getenv("SLFP_DW_OLD") != nullptr;
+    w.pw_nostg = std::getenv("SLFP_PW_NOSTG") != nullptr;
+    w.pw_notab = std::getenv("SLFP_PW_NOTAB") != nullptr;
+    const char* e = std::getenv("SLFP_PW_STG_MAXKS");
+    w.pw_stg_maxks = e ? atoi(e) : -1;
+    e = std::getenv("SLFP_PW_NT_MIN_MB");
+    w.pw_nt_min_mb = e ? atoll(e) : 0;
+    e = std::getenv("SLFP_DW_NT_MIN_MB");
+    w.dw_nt_min_mb = e ? atoll(e) : 120;
+    return w;
+}
+static Switches g_switches = read_switches();   // once, at load
+const Switches& switches() { return g_switches; }
+void reload_switches() { g_switches = read_switches(); }
+
 int device_cu_count() {
     static std::mutex mu;
     static std::map<int, int> cus;
@@ -68,6 +86,21 @@ int device_cu_count() {
     int n = 0;
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; }
     cus[dev] = n;
+    return n;
+}
+
+int resident_blocks_per_cu(const void* fn, int block_threads, size_t dynamic_lds) {
+    static std::mutex mu;
+    static std::map<std::pair<std::pair<int, const void*>, size_t>, int> cache;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 1; }
+    const auto key = std::make_pair(std::make_pair(dev, fn), dynamic_lds);
+    std::lock_guard<std::mutex> lock(mu);
+    const auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, block_threads, dynamic_lds) != hipSuccess || n < 1) { (void)hipGetLastError(); n = 1; }
+    cache[key] = n;
     return n;
 }
 
@@ -197,7 +230,8 @@ __global__ __launch_bounds__(kThreads) void k_absmax(const float* __restrict__ x
 static int grid_for(size_t n) {
     size_t blocks = (n / 4 + kThreads - 1) / kThreads;
     if (blocks < 1) blocks = 1;
-    if (blocks > 256 * 8) blocks = 256 * 8;  // 8 blocks per CU, grid-stride the rest
+    const size_t cap = (size_t)device_cu_count() * 8;  // 8 blocks per CU, grid-stride the rest
+    if (blocks > cap) blocks = cap;
     return (int)blocks;
 }
 
@@ -290,6 +324,7 @@ using namespace slfp;
 extern "C" {
 
 int slfp_version(void) { return SLFP_ABI_VERSION; }
+void slfp_debug_reload_switches(void) { reload_switches(); }
 const char* slfp_last_error(void) { return last_error_text(); }
 
 int slfp_device_count(void) {

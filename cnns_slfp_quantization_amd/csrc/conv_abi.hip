@@ -293,9 +293,7 @@ int slfp_conv2d_prepare_weights_codes(const slfp_conv2d_desc* d, const uint8_t* 
     return launch_prepare_weights(*d, p, reinterpret_cast<const float*>(codes_oihw), wprep, weight_q_oihw, as_stream(stream), true);
 }
 
-size_t slfp_conv2d_workspace_bytes(const slfp_conv2d_desc* d) {
-    ConvPlan p;
-    if (make_plan(d, &p) != SLFP_OK) return 0;
+static size_t workspace_bytes_for(const slfp_conv2d_desc* d, const ConvPlan& p) {
     size_t b = 0;
     if (d->x_layout == SLFP_LAYOUT_NCHW) b += round256((size_t)d->n * d->c_in * d->h * d->w * sizeof(float));
     if (d->y_layout == SLFP_LAYOUT_NCHW) b += round256((size_t)d->n * d->c_out * p.h_out * p.w_out * sizeof(float));
@@ -307,6 +305,12 @@ size_t slfp_conv2d_workspace_bytes(const slfp_conv2d_desc* d) {
         b += 3 * round256((size_t)p.cpo * sizeof(float));  // bias / post_scale / post_shift, padded
     }
     return b;
+}
+
+size_t slfp_conv2d_workspace_bytes(const slfp_conv2d_desc* d) {
+    ConvPlan p;
+    if (make_plan(d, &p) != SLFP_OK) return 0;
+    return workspace_bytes_for(d, p);
 }
 
 int slfp_conv2d_fwd(const slfp_conv2d_desc* d, const float* x, const void* wprep, const float* bias, float* y,
@@ -337,7 +341,7 @@ int slfp_conv2d_fwd_post(const slfp_conv2d_desc* d, const float* x, const void* 
         rc = launch_quantize(x, input_q, (size_t)d->n * d->c_in * d->h * d->w, d->ka, p.fmt_act, st);
         if (rc != SLFP_OK) return rc;
     }
-    const size_t ws_need = slfp_conv2d_workspace_bytes(d);
+    const size_t ws_need = workspace_bytes_for(d, p);   // the plan is built once per call
     if (ws_need && (!workspace || !aligned16(workspace)))
         return fail(SLFP_ERR_BAD_ARG, "slfp_conv2d_fwd: %zu bytes of 16-byte aligned workspace required (slfp_conv2d_workspace_bytes)", ws_need);
     unsigned char* ws = reinterpret_cast<unsigned char*>(workspace);

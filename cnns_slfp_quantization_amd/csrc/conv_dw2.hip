@@ -210,8 +210,7 @@ int launch_dw3x3_tile(const slfp_conv2d_desc& d, const ConvPlan& plan, const flo
     p.nblocks = (uint32_t)(ntiles * p.cgroups);
     p.ka = d.ka; p.kw = d.kw_scale;
     {   // SLFP_NT_DW bit 1 enables the policy; SLFP_DW_NT_MIN_MB moves the threshold (experiment switch; 0 = always nt)
-        const char* e = getenv("SLFP_DW_NT_MIN_MB");
-        const int64_t min_mb = e ? atoll(e) : 120;
+        const int64_t min_mb = switches().dw_nt_min_mb;
         p.nt_out = ((SLFP_NT_DW & 2) && (int64_t)p.N * p.Ho * p.Wo * p.C * 4 >= (min_mb << 20)) ? 1 : 0;
     }
     p.enc = *act_table(d.ka, plan.fmt_act, kEncF32);

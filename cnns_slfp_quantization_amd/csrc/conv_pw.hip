@@ -551,7 +551,7 @@ static int launch_tiled_k(PwParams& p, hipStream_t stream) {
     if constexpr (PASSES == 1) {
         if (p.enc.valid) {
             if constexpr (NT == 4) {
-                if (!getenv("SLFP_PW_NOSTG")) {   // per-call A/B switch (profiles/variants.py)
+                if (!switches().pw_nostg) {   // experiment switch (slfp_host.hpp), read once at load
                     const size_t lds = (size_t)2 * BM * 128 + (size_t)(T / 64) * 16 * kStgRow;   // dynamic part (the table is static LDS)
                     auto fn = k_pw_tiled<FMT, 1, WM, WN, MT, NT, KFULL, true, true>;
                     int rc = set_lds_limit(reinterpret_cast<const void*>(fn), lds);
@@ -589,9 +589,9 @@ static int launch_stream_ks(PwParams& p, hipStream_t stream) {
     // staged 128-byte stores (with the nt hint) pay where stores dominate and follow each other closely (K <= 64: pw1
     // -14 %, pw2 -13 %) and at K = 256 (256->256 @28: 113 -> 97-105 us); at K = 128 they lose 5-8 % (same-box A/B,
     // profiles/variants.py --var SLFP_PW_STG_MAXKS=4 / 8)
-    const char* mk = getenv("SLFP_PW_STG_MAXKS");   // experiment switch
-    const bool stg_ks = mk ? KS <= atoi(mk) : (KS <= 2 || KS == 8);
-    const bool stg = tab && stg_ks && !(p.K % 4 || p.N % 4) && !getenv("SLFP_PW_NOSTG");
+    const int mk = switches().pw_stg_maxks;   // experiment switch (slfp_host.hpp), read once at load
+    const bool stg_ks = mk >= 0 ? KS <= mk : (KS <= 2 || KS == 8);
+    const bool stg = tab && stg_ks && !(p.K % 4 || p.N % 4) && !switches().pw_nostg;
     const size_t lds = (size_t)(PASSES == 3 ? 2 : 1) * p.n_tiles * p.KS * 1024 + (size_t)3 * p.n_tiles * 16 * sizeof(float) +
                        (stg ? (size_t)(kStreamThreads / 64) * 2048 : 0);   // dynamic part; the table (2 KiB / 64 B) is static LDS
     const size_t lds_total = lds + (tab ? kPwTab : 64);
@@ -604,11 +604,12 @@ static int launch_stream_ks(PwParams& p, hipStream_t stream) {
     }
     int rc = set_lds_limit(reinterpret_cast<const void*>(fn), lds);
     if (rc != SLFP_OK) return rc;
-    // persistent grid: as many workgroups per CU as LDS allows (<= 4), 256 CUs
-    int per_cu = (int)((160 * 1024) / lds_total);
+    // persistent grid: as many workgroups per CU as LDS and registers allow (<= 4), on every CU of the device
+    int per_cu = resident_blocks_per_cu(reinterpret_cast<const void*>(fn), kStreamThreads, lds);
     per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+    (void)lds_total;
     const int64_t groups = (p.M + 15) / 16;
-    int64_t grid = 256 * per_cu;
+    int64_t grid = (int64_t)device_cu_count() * per_cu;
     const int64_t need = ceil_div(groups, kStreamThreads / 64);
     if (grid > need) grid = need;
     hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(kStreamThreads), lds, stream, p);
@@ -668,14 +669,13 @@ int launch_pointwise(const slfp_conv2d_desc& d, const ConvPlan& plan, const floa
     { const char* e = getenv("SLFP_PW_DBG"); p.dbg = e ? reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 16)) : nullptr; }
 #endif
     p.enc.valid = 0;
-    if (plan.passes == 1 && !getenv("SLFP_PW_NOTAB")) {   // SLFP_PW_NOTAB: per-call A/B switch (profiles/variants.py)
+    if (plan.passes == 1 && !switches().pw_notab) {   // experiment switch (slfp_host.hpp), read once at load
         if (const EncArgs* t = act_table(d.ka, plan.fmt_act, kEncF16P)) p.enc = *t;
     }
     p.s1 = plan.s1; p.s2 = plan.s2; p.s1x = plan.s1 * (1.0f / 256.0f);
     {   // staged stores always carry the nt hint: a size threshold as in conv_dw2.hip (plain stores for outputs that fit the
         // Infinity Cache) measured 1.5 % SLOWER on the whole net here (profiles/ab_env_wn.sh); SLFP_PW_NT_MIN_MB: experiment switch
-        const char* e = getenv("SLFP_PW_NT_MIN_MB");
-        const int64_t min_mb = e ? atoll(e) : 0;
+        const int64_t min_mb = switches().pw_nt_min_mb;
         p.nt_out = ((SLFP_NT_PW_STG & 2) && p.M * p.N * 4 >= (min_mb << 20)) ? 1 : 0;
     }
     if (plan.fmt_act == kFmtSfp7) return launch_pw<kFmtSfp7, 1>(p, plan, stream);  // exact in fp16

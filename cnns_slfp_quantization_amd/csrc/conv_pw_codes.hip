@@ -394,8 +394,9 @@ static int launch_pwc_stream(PwcParams& p, bool y_codes, hipStream_t stream) {
     auto fn = y_codes ? k_pwc_stream<FMT, KS, XW, true> : k_pwc_stream<FMT, KS, XW, false>;
     int rc = raise_lds_limit(reinterpret_cast<const void*>(fn), lds);
     if (rc != SLFP_OK) return rc;
-    int per_cu = (int)((160 * 1024) / lds_total);
+    int per_cu = resident_blocks_per_cu(reinterpret_cast<const void*>(fn), kPwcThreads, lds);
     per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+    (void)lds_total;
     const int64_t groups = (p.M + 15) / 16;
     int64_t grid = (int64_t)device_cu_count() * per_cu;
     const int64_t need = ceil_div(groups, kPwcThreads / 64);

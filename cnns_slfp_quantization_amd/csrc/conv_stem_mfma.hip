@@ -229,7 +229,7 @@ int launch_stem_mfma(const slfp_conv2d_desc& d, const ConvPlan& plan, const floa
     p.s1 = plan.s1; p.s2 = plan.s2; p.s1x = plan.s1 * (1.0f / 256.0f);
     const size_t lds = (size_t)p.KS * nt * 1024;
     const int occ = (int)std::max<size_t>(1, std::min<size_t>(2, (160 * 1024) / lds));
-    const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(p.units, kSmThreads / 64), 256 * occ);
+    const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(p.units, kSmThreads / 64), (int64_t)device_cu_count() * occ);
     return nt == 4 ? launch_stem_mfma_t<4>(p, lds, grid, stream) : launch_stem_mfma_t<6>(p, lds, grid, stream);
 }
 

@@ -39,14 +39,24 @@ inline ScaleDiv make_scale_div(float d, int esh = 0) {
     return s;
 }
 
-// SLFP_LONG_ENCODE=1 in the environment keeps every kernel on the long-form quantizer (slfp_device.hpp) instead of the
-// threshold table (slfp_enc.hpp): the A/B switch of profiles/ab_compare.sh and of the parity tests.
-inline bool long_encode_forced() {
-    static const bool v = std::getenv("SLFP_LONG_ENCODE") != nullptr;
-    return v;
-}
-// SLFP_DW_OLD=1: keep every depthwise layer on conv_dw.hip (A/B switch, profiles/variants.py); read per call.
-inline bool dw_old_forced() { return std::getenv("SLFP_DW_OLD") != nullptr; }
+// Experiment switches (profiles/*.sh, profiles/variants.py).  They are environment variables read ONCE, when the library is
+// first used (and again only on slfp_debug_reload_switches()): no getenv() is reachable from a launch.
+//   SLFP_LONG_ENCODE    keep every kernel on the long-form quantizer (slfp_device.hpp) instead of the threshold table
+//   SLFP_DW_OLD         keep every depthwise layer on conv_dw.hip
+//   SLFP_PW_NOSTG       pointwise kernels without the LDS-staged whole-line stores
+//   SLFP_PW_NOTAB       pointwise kernels on the long-form quantizer
+//   SLFP_PW_STG_MAXKS   stream kernel: staged stores up to this many k-steps (default: 1, 2 and 8)
+//   SLFP_PW_NT_MIN_MB / SLFP_DW_NT_MIN_MB   output size from which staged / depthwise stores carry the nt hint
+struct Switches {
+    bool long_encode, dw_old, pw_nostg, pw_notab;
+    int pw_stg_maxks;         // -1: default rule
+    long long pw_nt_min_mb;   // default 0
+    long long dw_nt_min_mb;   // default 120
+};
+const Switches& switches();
+void reload_switches();
+inline bool long_encode_forced() { return switches().long_encode; }
+inline bool dw_old_forced() { return switches().dw_old; }
 // The table for the activation side of a layer, or nullptr when the long form has to be used.
 inline const EncArgs* act_table(float ka, int fmt_act, int rep) {
     if (long_encode_forced()) return nullptr;
@@ -97,6 +107,9 @@ struct CodeIo {
     float y_ka;
     int y_fmt;        // kFmtAct8 | kFmtSfp7
 };
+// Workgroups of `fn` (block size, dynamic LDS) that fit one CU at once (hipOccupancyMaxActiveBlocksPerMultiprocessor, cached
+// per device / function / LDS size): how persistent grids are sized.  >= 1.
+int resident_blocks_per_cu(const void* fn, int block_threads, size_t dynamic_lds);
 // Number of compute units of the current device (cached per device; 256 on MI355X): persistent grids are sized from it.
 int device_cu_count();
 // pointwise on codes (conv_pw_codes.hpp): codes in, codes or float32 out; the SAME prepared blob as launch_pointwise

@@ -12,9 +12,11 @@
  * exceptions (an assert at sfp_quant.py:138 and shape errors from F.conv2d); the host
  * binding maps non-zero statuses to the same exception types.
  *
- * Threading: no global mutable state except a thread-local last-error string; safe to
- * call from any host thread; one device per process is assumed (multi-GPU = one process
- * per GPU, as torch.distributed/RCCL launches them).
+ * Threading: no mutable state on the launch path except a thread-local last-error string and lock-protected caches of
+ * derived constants (threshold tables per scale, occupancy / CU count per device); safe to call from any host thread; one
+ * device per process is assumed (multi-GPU = one process per GPU, as torch.distributed/RCCL launches them).
+ * Environment: a handful of SLFP_* experiment switches (csrc/slfp_host.hpp: Switches) are read ONCE when the library is
+ * loaded -- never per launch; slfp_debug_reload_switches() re-reads them (profiling tools only).
  */
 #ifndef SLFP_H_
 #define SLFP_H_
@@ -53,6 +55,8 @@ extern "C" {
 #define SLFP_MFMA_F16X3 3   /* hi/lo split, three passes: float32-equivalent (~1e-6) */
 
 int slfp_version(void);
+/* Re-reads the SLFP_* experiment switches from the environment (profiles/variants.py); not for production use. */
+void slfp_debug_reload_switches(void);
 /* Text of the last error on the calling thread ("" if none). Never NULL. */
 const char* slfp_last_error(void);
 /* Number of visible HIP devices (0 if none / runtime unavailable). */

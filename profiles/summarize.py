@@ -63,7 +63,9 @@ def load_trace(d):
 
 def main():
     tag = sys.argv[1]
-    what = sys.argv[2] if len(sys.argv) > 2 else "MobileNetV1-224 SLFP<3,4>, batch 256"
+    if len(sys.argv) < 3:
+        raise SystemExit("usage: summarize.py TAG \"what was profiled (command, net, batch)\"  -- the title is not guessed")
+    what = sys.argv[2]
     base = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     dur = load_trace(os.path.join(base, "stats"))
     counters = {}
@@ -113,7 +115,7 @@ def main():
     cols = ["kernel", "grid_threads", "launches", "avg_us", "vgpr", "agpr", "lds", "hbm_read_MB", "hbm_write_MB", "hbm_GBps",
             "valu_active_frac", "wait_any_frac", "lds_conflict_frac", "mfma_busy_frac", "valu_insts_per_wave"]
     with open(os.path.join(ROOT, "profiles", f"{tag}_summary.md"), "w") as f:
-        f.write(f"# rocprofv3 summary `{tag}` (bench.py, {what}, 1x MI355X)\n\n")
+        f.write(f"# rocprofv3 summary `{tag}` ({what}, 1x MI355X)\n\n")
         f.write("Source: `profiles/run_profile.sh` (kernel-trace --stats pass + separate --pmc passes). "
                 "hbm_read_MB = 2 x FETCH_SIZE (gfx950 correction), hbm_write_MB = WRITE_SIZE.\n\n")
         f.write("| " + " | ".join(cols) + " |\n|" + "---|" * len(cols) + "\n")

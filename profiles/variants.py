@@ -7,8 +7,8 @@ Times every layer of the chosen kernel family (MobileNetV1-224, batch 256 by def
 default library behaviour and for each --var setting, in interleaved rounds (cdna guide rule 24: one process, one
 device), and prints median microseconds and algorithmic GB/s.  Within a round the layers run ONCE each, in order, like a
 bench.py step: a layer that is launched several times back to back finds its 100-200 MB of input and output in the
-256 MiB Infinity Cache and looks 20-25 % faster than it is in the net (--warm restores that behaviour).  Only switches that the library reads at launch time
-work here (SLFP_DW_OLD, SLFP_DW_ABLATE, SLFP_PW_*); SLFP_LONG_ENCODE is read once per process (use ab_env.sh).
+256 MiB Infinity Cache and looks 20-25 % faster than it is in the net (--warm restores that behaviour).  The library reads its switches once at load; this tool calls
+slfp_debug_reload_switches() after changing the environment (SLFP_DW_OLD, SLFP_PW_*, SLFP_LONG_ENCODE with care: tables are cached).
 """
 import argparse
 import os
@@ -53,6 +53,7 @@ def main():
             for k in keys:
                 os.environ.pop(k, None)
             os.environ.update(env)
+            L.slfp_debug_reload_switches()   # the library reads its switches once at load; this re-reads them
             reps = 3 if args.warm else 1
             evs = []
             for i, l in enumerate(layers):

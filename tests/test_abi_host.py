@@ -327,3 +327,22 @@ def test_product_never_imports_the_oracle():
     bench = open(os.path.join(ROOT, "bench.py")).read()
     # bench.py: exactly one import, inside cpu_baseline()
     assert bench.count("from oracle") == 1 and bench.split("from oracle")[0].rsplit("\ndef ", 1)[-1].startswith("cpu_baseline(")
+
+
+def test_no_getenv_on_the_launch_path():
+    """experiment switches are read once at load (csrc/codec.hip: read_switches), never per launch.
+    The only other getenv sits inside the SLFP_PW_STAMPS diagnostic build."""
+    csrc = os.path.join(ROOT, "cnns_slfp_quantization_amd", "csrc")
+    hits = []
+    for f in sorted(os.listdir(csrc)):
+        text = open(os.path.join(csrc, f)).read()
+        allowed = (0, 0)
+        if f == "codec.hip":
+            allowed = (text.index("static Switches read_switches"), text.index("static Switches g_switches"))
+        for m in re.finditer(r"getenv\s*\(", text):
+            if allowed[0] < m.start() < allowed[1]:
+                continue
+            if "SLFP_PW_STAMPS" in text[max(0, m.start() - 200):m.start()] or text[:m.start()].rsplit("\n", 1)[-1].lstrip().startswith("//"):
+                continue   # the diagnostic build, or a comment that documents the rule
+            hits.append((f, text[:m.start()].count("\n") + 1))
+    assert not hits, hits
