@@ -24,12 +24,20 @@ def shard_range(total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def broadcast_blobs(blobs, src=0, group=None):
+def _single(group, force):
+    """No process group, or a world of one: the collectives are the identity -- unless `force` asks for the call to go
+    through the backend anyway (a one-rank RCCL collective is legal: tests/test_gpu_rccl.py runs the real code path)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return True
+    return dist.get_world_size(group) == 1 and not force
+
+
+def broadcast_blobs(blobs, src=0, group=None, force=False):
     """Broadcast a list of uint8 tensors (the per-layer prepared weight blobs) from `src`
     as ONE flat bucket; the tensors are overwritten in place on the other ranks."""
     if not blobs:
         return blobs
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _single(group, force):
         return blobs
     sizes = [int(b.numel()) for b in blobs]
     flat = torch.empty(sum(sizes), dtype=torch.uint8, device=blobs[0].device)
@@ -46,9 +54,9 @@ def broadcast_blobs(blobs, src=0, group=None):
     return blobs
 
 
-def gather_outputs(local, group=None):
+def gather_outputs(local, group=None, force=False):
     """Optional final all-gather of per-rank outputs (e.g. logits) along dim 0."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _single(group, force):
         return local
     parts = [torch.empty_like(local) for _ in range(dist.get_world_size(group))]
     dist.all_gather(parts, local.contiguous(), group=group)
@@ -64,10 +72,10 @@ def per_rank_batch(batch, global_batch, rank, world):
     return rank * batch, (rank + 1) * batch, False
 
 
-def rank_times(seconds, device=None, group=None):
+def rank_times(seconds, device=None, group=None, force=False):
     """Every rank's timed-region seconds, on every rank: the job's time is the MAX (the slowest rank), and the
     rank-0 line reports all of them."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _single(group, force):
         return [float(seconds)]
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     parts = [torch.zeros_like(t) for _ in range(dist.get_world_size(group))]
