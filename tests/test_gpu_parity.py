@@ -1207,3 +1207,111 @@ def test_zz_elementwise_error_fractions_per_kernel_family():
         frac = bad / max(n, 1)
         print(f"elementwise |d| > 1e-3 |ref|: {kern:28s} {frac:9.2e}  ({n} outputs)")
         assert frac <= (0.25 if kern.endswith("_f16x1") else 5e-3), (kern, frac)
+
+
+# ------------------------------------------------------------------ BASELINE configs 3-5 end to end (round 3)
+def _build_r3(net, dev, qbits=None, channels_last=True):
+    """The topology of `net` (tests/golden/netgen_r3.py: this repo's own definition, proven equal to the reference's net on
+    the reference's operators when the fixture was generated) out of the drop-in modules, with the fixture's name-seeded
+    parameters, BatchNorm statistics, weight gains and per-module scales."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import netgen_r3 as ng
+    import utils.conv2d_func as cf
+    import utils.sfp_quant as sq
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "nets_r3_golden.npz"))
+    q, batch, in_seed, seed = [int(v) for v in gold[f"{net}:meta"]]
+    manifest = json.loads(bytes(gold[f"{net}:manifest"]).decode())
+    gains = json.loads(bytes(gold[f"{net}:gains"]).decode())
+    f = ng.Factories(cf, qbits or q, manifest, layerout=sq.layerout_quantize_func)
+    m = ng.BUILDERS[net](f)
+    ng.fill_parameters_by_name(m, seed, gains)
+    ng.load_bn_stats_by_name_(m, {k[len(net) + 1:]: gold[k] for k in gold.files if k.startswith(f"{net}:bn:")})
+    m = m.to(dev).eval()
+    x = ng.net_input224(batch, in_seed).to(dev)
+    if channels_last:
+        m = m.to(memory_format=torch.channels_last)
+        x = x.contiguous(memory_format=torch.channels_last)
+    tap = {"resnet50": "layer2", "squeezenet": "features.5", "vgg16": "layer3", "shufflenetv2": "stage3"}[net]
+    return m, x, gold, dict(m.named_modules())[tap]
+
+
+# (max-rel, l2) bars on the logits and on the mid-network activation.  Chained layers amplify single code flips (SURVEY
+# section 7), deeper nets more.  The yardstick is the reference against ITSELF with another summation order (the fixture's
+# net re-run on the CPU with oneDNN disabled, round 3): ResNet-50 logits move 5.1e-2 / 4.9e-2, VGG-16 2.8e-2 / 3.1e-2; the
+# bars are about twice that.  Measured on the MI355X (logits; mid): ResNet-50 F16X3 7.8e-2 / 6.3e-2; 7.1e-2 / 4.0e-2,
+# VGG-16 F16X3 2.8e-2 / 3.0e-2, F16X1 4.0e-2 / 4.3e-2; SqueezeNet (SFP<3,3>, exact products) 3.5e-3 / 2.4e-3;
+# ShuffleNetV2 (SFP<3,3> + layer-output quantizers) 1.5e-2 / 1.1e-2.  The single-pass fp16 mode (F16X1) is inside the per-layer
+# 1e-3 bar but its operand rounding compounds over ResNet-50's 53 layers: logits 1.0e-1 / 1.0e-1, top-1 agrees on 3 of 4
+# images, about twice the float32-equivalent mode's distance from the fixture (DESIGN.md section 2).
+R3_BARS = {
+    # net: {passes: (logits max, logits l2, mid max, mid l2)}
+    "resnet50": {3: (0.11, 0.10, 0.25, 8e-2), 1: (0.2, 0.2, 0.35, 0.25)},   # F16X1: 1.0e-1 / 1.0e-1; mid 0.16 / 0.13; top-1 3 of 4
+    "vgg16": {3: (6e-2, 6.5e-2, 0.25, 6e-2), 1: (8e-2, 8e-2, 0.3, 0.1)},
+    "squeezenet": {1: (3e-2, 2e-2, 0.2, 3e-2)},
+    "shufflenetv2": {1: (6e-2, 4e-2, 0.3, 6e-2)},
+}
+
+
+@pytest.mark.parametrize("net", ["squeezenet", "shufflenetv2", "vgg16", "resnet50"])
+def test_whole_net_configs_3_to_5_against_reference_fixture(dev, net):
+    """nets_imgnet/resnet50.py:24-147, squeezenet1_0.py:21-95, nets_cifar/vgg16.py:13-135, shufflenet_v2.py:22-167 end to
+    end at 224x224 against tests/golden/nets_r3_golden.npz (the reference's own logits and one mid-network activation):
+    NCHW and channels_last, both MFMA modes for the SLFP<3,4> nets, SFP<3,3> for the config-5 nets; ResNet-50 also with
+    its conv<k>/bn<k> pairs folded (fusion.fuse_named_bn) and SqueezeNet / VGG / ShuffleNetV2 with fuse_bn_relu."""
+    import utils.conv2d_func as cf
+    from cnns_slfp_quantization_amd import fusion
+    try:
+        for passes, bars in R3_BARS[net].items():
+            cf.options.mfma_passes = passes
+            for cl in (True, False):
+                m, x, gold, tap = _build_r3(net, dev, channels_last=cl)
+                feats = {}
+                h = tap.register_forward_hook(lambda mod, i, o: feats.__setitem__("mid", o.detach()[:2, ::8, ::4, ::4].cpu().numpy()))
+                with torch.no_grad():
+                    L = m(x).cpu().numpy()
+                h.remove()
+                G, Gm = gold[f"{net}:logits"], gold[f"{net}:mid"]
+                el, em = rel_errors(L, G), rel_errors(feats["mid"], Gm)
+                top1 = float((L.argmax(1) == G.argmax(1)).mean())
+                top5 = float(np.mean([len(set(np.argsort(-a)[:5]) & set(np.argsort(-b)[:5])) for a, b in zip(L, G)]))
+                print(f"{net} passes={passes} {'channels_last' if cl else 'nchw'}: logits {el}, mid {em}, top1 {top1}, top5 overlap {top5}/5")
+                assert np.isfinite(L).all()
+                assert el[0] <= bars[0] and el[1] <= bars[1], (net, passes, cl, el)
+                assert em[0] <= bars[2] and em[1] <= bars[3], (net, passes, cl, em)
+                assert top1 >= (0.5 if (net == "resnet50" and passes == 1) else 1.0) and top5 >= 3.5, (net, passes, top1, top5)
+                if cl:   # the fused forms against the unfused net of the same mode (not against the fixture)
+                    with torch.no_grad():
+                        n_fused = fusion.fuse_named_bn(m, x) if net == "resnet50" else fusion.fuse_bn_relu(m)
+                        Lf = m(x).cpu().numpy()
+                    ef = rel_errors(Lf, L)
+                    print(f"   fused ({n_fused} convs): vs unfused {ef}")
+                    assert n_fused > 0 or net == "squeezenet"
+                    assert ef[0] <= bars[0] and ef[1] <= bars[1], (net, "fused", ef)
+    finally:
+        cf.options.mfma_passes = 0
+
+
+def test_conv2d_Q_raw_bias_forward_against_reference_fixture(lib, dev):
+    """conv2d_Q(bias=True) hands the UNSCALED bias to F.conv2d: (conv(input_q, weight_q) + b) * Ka * Kw
+    (utils/conv2d_func.py:23-24).  tests/golden/rawbias_golden.npz holds the reference's outputs."""
+    import utils.conv2d_func as cf
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rawbias_golden.npz"))
+    try:
+        for passes in (3, 1):
+            cf.options.mfma_passes = passes
+            for name in ("dw", "pw", "dense"):
+                N, C, H, W, O, k, s, p, g = [int(v) for v in gold[f"{name}_meta"]]
+                Ka, Kw = [np.float64(v) for v in gold[f"{name}_scales"]]
+                for q in (8, 7):
+                    m = cf.conv2d_Q(q_bit=q, Kw=Kw, Ka=Ka)(C, O, k, Kw, Ka, s, p, groups=g, bias=True).eval().to(dev)
+                    with torch.no_grad():
+                        m.weight.copy_(torch.from_numpy(gold[f"{name}_w"]))
+                        m.bias.copy_(torch.from_numpy(gold[f"{name}_b"]))
+                        y = m(torch.from_numpy(gold[f"{name}_x"]).to(dev)).cpu().numpy()
+                    e = rel_errors(y, gold[f"{name}_y_q{q}"])
+                    tol = TOL_F16X1 if (passes == 1 and q == 8 and name != "dw") else TOL_EXACT
+                    assert max(e) <= tol, (name, q, passes, e)
+    finally:
+        cf.options.mfma_passes = 0
