@@ -69,6 +69,10 @@ static Switches read_switches() {
     w.pw_nt_min_mb = e ? atoll(e) : 0;
     e = std::getenv("SLFP_DW_NT_MIN_MB");
     w.dw_nt_min_mb = e ? atoll(e) : 120;
+    w.stem_old = std::getenv("SLFP_STEM_OLD") != nullptr;
+    w.stem_mx = std::getenv("SLFP_STEM_MX") != nullptr;
+    e = std::getenv("SLFP_PW_STREAM_MAX_KB");
+    w.pw_stream_max_kb = e ? atoi(e) : 128;
     return w;
 }
 static Switches g_switches = read_switches();   // once, at load

@@ -438,6 +438,164 @@ __global__ __launch_bounds__(256) void k_stem_fixed(const float* __restrict__ x,
     }
 }
 
+// ======================================================================================
+// k_stem_mx: the MobileNetV1 stem (3x3 s2, 3 -> 32, nets_imgnet/mobilenetv1.py:44) on the FLOAT32 matrix cores (round 3).
+// k_stem_fixed spends 27 float32 FMAs per output element on the vector ALU and is VALU-issue-bound (33 VALU instructions
+// per output, profiles/r03c0: the kernel takes the same 122 us whether it writes float32 or 4x smaller codes).
+// v_mfma_f32_16x16x4_f32 multiplies float32 operands exactly and accumulates in float32 in k order, i.e. the same fused
+// multiply-add chain (kh, kw, c) the vector kernel runs -- outputs are bit-identical (tests/test_gpu_parity.py) -- at 1024
+// multiply-adds per instruction, on a pipe that runs beside the vector ALU:
+//   A = W [16 output channels x 4 taps], B = input patches [4 taps x 16 pixels] from the quantized float32 halo tile in LDS
+//   (one ds_read_b32 per k-step per lane), 7 k-steps (27 taps + one zero tap) x 2 channel tiles per 16 output pixels.
+//   A's rows are channels in the order 8 (r / 4) + 4 t + r % 4 for tile t, so a lane ends up with 8 CONSECUTIVE channels
+//   of its pixel: float32 output is staged through LDS into whole 1 KiB runs (8 pixels x 128 B per store instruction),
+//   code output (YC) is one 8-byte store per lane (a wave: 512 contiguous bytes).
+// One workgroup = one image, a 16 x 16 output tile; a wave owns 4 tile rows = 4 units of 16 pixels.
+// ======================================================================================
+template <bool YC>
+__global__ __launch_bounds__(256) void k_stem_mx(const float* __restrict__ x, const float* __restrict__ wq,
+                                                 const float* __restrict__ bias, float* __restrict__ y, const StemParams p) {
+    constexpr int KH = 3, KW = 3, C = 3, S = 2, O = 32, TH = 16;
+    constexpr int IH = (TH - 1) * S + KH, IWC = ((kStemTW - 1) * S + KW) * C;   // 33 rows x 99 floats
+    constexpr int N_IN = IH * IWC, U = (N_IN + 255) / 256;
+    typedef float f32x4m __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) float tile[N_IN + 1];   // [IH][IWC] + one zero word (the 28th tap)
+    __shared__ __attribute__((aligned(16))) uint32_t sT[2 * (kEncEntries + 1)];
+    __shared__ __attribute__((aligned(16))) unsigned char senc[YC ? ((kEncEntries * 8 + 15) & ~15) : 16];
+    constexpr int SP = 36;   // staging row pitch in floats: 128 B of channels + 16 B, so the 16 pixels' float4 writes spread over the banks
+    __shared__ __attribute__((aligned(16))) float stg[YC ? 4 : 4 * 16 * SP];   // float32 output: one 16-pixel unit per wave
+    enc_fill<256>(reinterpret_cast<uint2*>(sT), p.enc);
+    if constexpr (YC) enc_fill_compact<256>(reinterpret_cast<uint2*>(senc), p.enc_out);
+    if (threadIdx.x == 0) tile[N_IN] = 0.f;
+
+    uint32_t b = xcd_remap(blockIdx.x, p.nblocks);
+    const int tw = b % p.tiles_w; b /= p.tiles_w;
+    const int th = b % p.tiles_h; b /= p.tiles_h;
+    const int n = b;
+    const int h_in0 = th * TH * S - p.ph, w_in0 = tw * kStemTW * S - p.pw;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int px = lane & 15, kq = lane >> 4;
+    // A fragments: W[k = 4 ks + kq][channel of row px of tile t], 7 k-steps x 2 tiles, once per workgroup
+    float wa[7][2];
+#pragma unroll
+    for (int ks = 0; ks < 7; ++ks) {
+        const int k = 4 * ks + kq;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) wa[ks][t] = k < KH * KW * C ? wq[k * O + 8 * (px >> 2) + 4 * t + (px & 3)] : 0.f;
+    }
+    // byte offset of tap k = 4 ks + kq inside a pixel's window: (k / 9) rows + k % 9 floats; tap 27 is the zero word
+    uint32_t koff[7];
+#pragma unroll
+    for (int ks = 0; ks < 7; ++ks) {
+        const int k = 4 * ks + kq;
+        koff[ks] = (uint32_t)((k / (KW * C)) * IWC + (k % (KW * C))) * 4u;
+    }
+    __syncthreads();   // tables visible
+
+    {   // load + quantize the halo tile: rows are contiguous in NHWC, one dword per lane (as k_stem_fixed<.., TAB>)
+        const float* xn = x + (size_t)n * p.H * p.W * C;
+        const int j_lo = -w_in0 * C, j_hi = (p.W - w_in0) * C;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xn), 0, (uint32_t)p.H * p.W * C * 4u, 0x00020000);
+        uint32_t vo[U];
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = threadIdx.x + u * 256;
+            const int ih = idx / IWC, j = idx - ih * IWC;  // compile-time divisor
+            const int gh = h_in0 + ih;
+            const bool ok = idx < N_IN && (unsigned)gh < (unsigned)p.H && j >= j_lo && j < j_hi;
+            vo[u] = ok ? (uint32_t)((gh * p.W + w_in0) * C + j) * 4u : 0xFFFFFFF0u;
+            asm volatile("" : "+v"(vo[u]));
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vo[u], 0, 0));
+        const unsigned char* tb = reinterpret_cast<const unsigned char*>(sT);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = threadIdx.x + u * 256;
+            float q = enc_f32(v[u], p.enc.r1, p.enc.lo, p.enc.hi, tb);
+            q = v[u] != v[u] ? __uint_as_float(kBitsQNaN) : q;   // NaN in -> NaN out
+            if (idx < N_IN) tile[idx] = q;
+        }
+    }
+    __syncthreads();
+
+    // per-lane epilogue constants: this lane's 8 consecutive channels
+    const int c0 = 8 * kq;
+    float bq[8], psc[8], psh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        bq[e] = bias ? (bias[c0 + e] / p.s1) / p.s2 : 0.f;
+        psc[e] = p.post.scale ? p.post.scale[c0 + e] : 1.f;
+        psh[e] = p.post.scale ? p.post.shift[c0 + e] : 0.f;
+    }
+    const unsigned char* tbytes = reinterpret_cast<const unsigned char*>(tile);
+    const int gow = tw * kStemTW + px;
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+        const int row = wave * 4 + r4;
+        const uint32_t pbase = (uint32_t)((row * S) * IWC + px * S * C) * 4u;
+        f32x4m acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 7; ++ks) {
+            uint32_t a = pbase + koff[ks];
+            if (ks == 6) a = kq == 3 ? (uint32_t)N_IN * 4u : a;   // tap 27 does not exist: the zero word
+            const float xb = *reinterpret_cast<const float*>(tbytes + a);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[ks][0], xb, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[ks][1], xb, acc1, 0, 0, 0);
+        }
+        float r[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float u = (((e < 4 ? acc0[e] : acc1[e - 4]) + bq[e]) * p.s1) * p.s2;
+            if (p.post.scale) {
+                u = __builtin_fmaf(u, psc[e], psh[e]);
+                if (p.post.layerout) u = layerout1(u);
+            }
+            r[e] = u;
+        }
+        const int goh = th * TH + row;
+        const bool live = goh < p.Ho && gow < p.Wo;
+        if constexpr (YC) {
+            uint32_t cA, cB;
+            const float4 ra = make_float4(r[0], r[1], r[2], r[3]), rb = make_float4(r[4], r[5], r[6], r[7]);
+            if (p.sgn) {
+                cA = enc4_code<true>(ra, p.enc_out.r1, p.enc_out.lo, p.enc_out.hi, senc);
+                cB = enc4_code<true>(rb, p.enc_out.r1, p.enc_out.lo, p.enc_out.hi, senc);
+                if (p.fmt_out == kFmtSfp7) {
+                    cA = (cA & 0x3F3F3F3Fu) | ((cA & 0x80808080u) >> 1);
+                    cB = (cB & 0x3F3F3F3Fu) | ((cB & 0x80808080u) >> 1);
+                }
+            } else {   // the ReLU is the quantizer's
+                cA = enc4_code_relu(ra, p.enc_out.r1, p.enc_out.lo, p.enc_out.hi, senc);
+                cB = enc4_code_relu(rb, p.enc_out.r1, p.enc_out.lo, p.enc_out.hi, senc);
+            }
+            if (live) {
+                uint8_t* yc = reinterpret_cast<uint8_t*>(y) + (((size_t)n * p.Ho + goh) * p.Wo + gow) * O + c0;
+                *reinterpret_cast<uint2*>(yc) = make_uint2(cA, cB);
+            }
+        } else {
+            if (p.post.relu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) r[e] = fmaxf(r[e], 0.f);
+            }
+            // stage the unit (16 pixels x 32 channels = 2 KiB) so that each store instruction writes 8 whole pixels
+            float* sw = stg + wave * (16 * SP);
+            *reinterpret_cast<float4*>(sw + px * SP + c0) = make_float4(r[0], r[1], r[2], r[3]);
+            *reinterpret_cast<float4*>(sw + px * SP + c0 + 4) = make_float4(r[4], r[5], r[6], r[7]);
+            // LDS operations of one wave execute in order: the reads below see the writes above
+            float* yrow = y + (((size_t)n * p.Ho + goh) * p.Wo + tw * kStemTW) * O;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int spx = h * 8 + (lane >> 3);
+                const float4 vv = *reinterpret_cast<const float4*>(sw + spx * SP + (lane & 7) * 4);
+                if (goh < p.Ho && tw * kStemTW + spx < p.Wo) st_stream4<SLFP_NT_STEM>(yrow + spx * O + (lane & 7) * 4, vv);
+            }
+        }
+    }
+}
+
 bool stem_applicable(const slfp_conv2d_desc& d) {
     const int O = (int)d.c_out, C = (int)d.c_in;
     if (d.groups != 1 || C > 4 || d.dil_h != 1 || d.dil_w != 1 || d.stride_h != d.stride_w || d.stride_h > 4) return false;
@@ -479,13 +637,22 @@ static int try_launch_stem(const slfp_conv2d_desc& d, const ConvPlan& plan, cons
             constexpr int TH = 16;
             p.tiles_h = (int)ceil_div(p.Ho, TH);
             p.nblocks = (uint32_t)((int64_t)p.N * p.tiles_h * p.tiles_w);
+            // float32 matrix-core stem (k_stem_mx): measured (round 3, same box) 121.6 vs 131.4 us with code output, 121.4 vs
+            // 118.9 us with float32 output (both HBM-side bound there) -> default for code output only; SLFP_STEM_MX forces it
+            // for float32 output too, SLFP_STEM_OLD keeps the vector kernel everywhere.  Bit-identical either way.
+            const bool mx = !switches().stem_old;
+            if (mx && switches().stem_mx && !(io && io->y_codes)) {
+                hipLaunchKernelGGL((k_stem_mx<false>), dim3(p.nblocks), dim3(256), 0, stream, x, wq_hwio, bias, y, p);
+                return check_launch("slfp stem conv kernel (3x3x3 s2 -> 32, float32 MFMA)");
+            }
             if (io && io->y_codes) {   // output as the next layer's codes (slfp_conv2d_fwd_codes)
                 const EncArgs* tc = enc_table(io->y_ka, io->y_fmt, kEncCode);
                 if (!tc->valid) return fail(SLFP_ERR_UNSUPPORTED, "stem (codes): no code table for the consumer's scale %g", (double)io->y_ka);
                 p.enc_out = enc_compact(*tc);
                 p.sgn = post.relu ? 0 : 1;
                 p.fmt_out = io->y_fmt;
-                hipLaunchKernelGGL((k_stem_fixed<kFmtAct8, 3, 3, 3, 2, 32, true, TH, true>), dim3(p.nblocks), dim3(256), 0, stream, x, wq_hwio, bias, y, p);
+                if (mx) hipLaunchKernelGGL((k_stem_mx<true>), dim3(p.nblocks), dim3(256), 0, stream, x, wq_hwio, bias, y, p);
+                else hipLaunchKernelGGL((k_stem_fixed<kFmtAct8, 3, 3, 3, 2, 32, true, TH, true>), dim3(p.nblocks), dim3(256), 0, stream, x, wq_hwio, bias, y, p);
                 return check_launch("slfp stem conv kernel (3x3x3 s2 -> 32, codes out)");
             }
             hipLaunchKernelGGL((k_stem_fixed<kFmtAct8, 3, 3, 3, 2, 32, true, TH>), dim3(p.nblocks), dim3(256), 0, stream, x, wq_hwio, bias, y, p);

@@ -619,7 +619,7 @@ static int launch_stream_ks(PwParams& p, hipStream_t stream) {
 // W small enough to live in LDS next to nothing else?
 bool pointwise_stream_fits(int64_t k_pad, int64_t n_pad, int passes) {
     const size_t w = (size_t)k_pad * n_pad * 2 * (passes == 3 ? 2 : 1);
-    return k_pad <= 256 && w <= 128 * 1024;
+    return k_pad <= 256 && w <= (size_t)switches().pw_stream_max_kb * 1024;
 }
 static bool stream_fits(const ConvPlan& plan, int passes) { return pointwise_stream_fits(plan.k_pad, plan.n_pad, passes); }
 

@@ -52,6 +52,9 @@ struct Switches {
     int pw_stg_maxks;         // -1: default rule
     long long pw_nt_min_mb;   // default 0
     long long dw_nt_min_mb;   // default 120
+    bool stem_mx;             // SLFP_STEM_MX: the float32 MFMA stem also for float32 output (default: code output only)
+    bool stem_old;            // SLFP_STEM_OLD: the MobileNetV1 stem on the vector ALU (k_stem_fixed) instead of the float32 MFMA kernel
+    int pw_stream_max_kb;     // SLFP_PW_STREAM_MAX_KB: largest W (KiB, fp16) the LDS-resident stream kernel takes (default 128)
 };
 const Switches& switches();
 void reload_switches();

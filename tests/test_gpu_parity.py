@@ -1315,3 +1315,52 @@ def test_conv2d_Q_raw_bias_forward_against_reference_fixture(lib, dev):
                     assert max(e) <= tol, (name, q, passes, e)
     finally:
         cf.options.mfma_passes = 0
+
+
+def test_stem_float32_mfma_is_bit_identical_to_the_vector_kernel(lib, dev):
+    """Round 3: the MobileNetV1 stem (nets_imgnet/mobilenetv1.py:44) can run its 27-tap float32 FMA chain on
+    v_mfma_f32_16x16x4_f32 (csrc/conv_direct.hip: k_stem_mx; the default when the output leaves as 1-byte codes).  The
+    instruction multiplies float32 exactly and accumulates in k order, so the result must equal the vector kernel's bit for
+    bit -- with and without the fused BatchNorm + ReLU, full and ragged tiles, NaN inputs -- and sit within float32
+    round-off of the oracle."""
+    from cnns_slfp_quantization_amd import layer_specs
+    L = lib.load()
+    s = layer_specs.conv_layers("mobilenetv1_imagenet224")[0]
+    gen = torch.Generator(device=dev).manual_seed(31)
+    try:
+        for (n, h, w) in ((3, 224, 224), (2, 70, 54), (1, 33, 31)):
+            d = lib.ConvDesc(n=n, c_in=3, h=h, w=w, c_out=32, kh=3, kw=3, stride_h=2, stride_w=2, pad_h=1, pad_w=1, dil_h=1, dil_w=1,
+                             groups=1, x_layout=lib.LAYOUT_NHWC, y_layout=lib.LAYOUT_NHWC, qbits=8, ka=float(np.float32(s.Ka)),
+                             kw_scale=float(np.float32(s.Kw)), mfma_passes=0, reserved=0)
+            ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+            x = torch.randn((n, h, w, 3), generator=gen, device=dev) * (4.0 * s.Ka)
+            wt = torch.randn((32, 3, 3, 3), generator=gen, device=dev) * (4.0 * s.Kw)
+            blob = torch.empty(L.slfp_conv2d_wprep_bytes(ctypes.byref(d)), dtype=torch.uint8, device=dev)
+            lib.check(L.slfp_conv2d_prepare_weights(ctypes.byref(d), wt.data_ptr(), blob.data_ptr(), None, _stream()))
+            sc = torch.rand(32, generator=gen, device=dev) + 0.5
+            sh = torch.randn(32, generator=gen, device=dev) * 0.2
+            ref = so.conv2d(x.cpu().numpy().transpose(0, 3, 1, 2), wt.cpu().numpy(), None, 2, 1, 1, 1, np.float64(s.Ka), np.float64(s.Kw), 8)
+            xn = x.clone()
+            xn.view(-1)[7::1001] = float("nan")
+            outs = {}
+            for mx in (True, False):
+                os.environ.pop("SLFP_STEM_MX", None)
+                os.environ.pop("SLFP_STEM_OLD", None)
+                os.environ["SLFP_STEM_MX" if mx else "SLFP_STEM_OLD"] = "1"
+                L.slfp_debug_reload_switches()
+                for post in (False, True):
+                    for xin, tag in ((x, "clean"), (xn, "nan")):
+                        y = torch.empty((n, ho, wo, 32), device=dev)
+                        lib.check(L.slfp_conv2d_fwd_post(ctypes.byref(d), xin.data_ptr(), blob.data_ptr(), None, sc.data_ptr() if post else None,
+                                                         sh.data_ptr() if post else None, 1 if post else 0, y.data_ptr(), None, None, _stream()))
+                        outs[(mx, post, tag)] = y.cpu().numpy()
+            for post in (False, True):
+                for tag in ("clean", "nan"):
+                    assert same_bits(outs[(True, post, tag)], outs[(False, post, tag)]), (n, h, w, post, tag)
+            assert np.isnan(outs[(True, False, "nan")]).any()
+            y = outs[(True, False, "clean")].transpose(0, 3, 1, 2)
+            assert np.abs(y - ref).max() <= 1e-5 * np.abs(ref).max()
+    finally:
+        os.environ.pop("SLFP_STEM_OLD", None)
+        os.environ.pop("SLFP_STEM_MX", None)
+        L.slfp_debug_reload_switches()
