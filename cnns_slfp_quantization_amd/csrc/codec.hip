@@ -71,6 +71,11 @@ static Switches read_switches() {
     w.dw_nt_min_mb = e ? atoll(e) : 120;
     w.stem_old = std::getenv("SLFP_STEM_OLD") != nullptr;
     w.stem_mx = std::getenv("SLFP_STEM_MX") != nullptr;
+    w.pwc_slice = std::getenv("SLFP_PWC_NOSLICE") == nullptr;
+    e = std::getenv("SLFP_DENSE_CFG");
+    w.dense_cfg = e ? atoi(e) : 0;
+    e = std::getenv("SLFP_DENSE_NWB");
+    w.dense_nwb = e ? atoi(e) : 0;
     e = std::getenv("SLFP_PW_STREAM_MAX_KB");
     w.pw_stream_max_kb = e ? atoi(e) : 128;
     return w;

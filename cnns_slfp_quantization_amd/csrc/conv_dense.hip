@@ -117,14 +117,21 @@ __global__ __launch_bounds__(256) void k_dense_encode(const float* __restrict__ 
 // PASSES == 3 (float32-equivalent): both operands carry an fp16 residual plane (hi + lo), staged next to
 // the hi planes, and every tile takes 3 MFMAs (lo*hi + hi*lo + hi*hi), as the pointwise kernels do.
 // NSLOT: halo pieces a wave stages per chunk (3 covers every 3x3 stride-1 tiling; 9 the rest).
-template <int WM, int WN, int MT, int PASSES, int NSLOT>
+// NWB: weight-tile buffers.  2: the tile two taps ahead is requested into the buffer freed by this tap's barrier and must have
+// LANDED by the next tap's barrier (s_waitcnt vmcnt(0)): a one-tap flight window (16-32 MFMAs, ~0.25 us) against an L2 round
+// trip of ~1 us -- the matrix pipe idles 50-80 % of the time on the one-workgroup-per-CU tilings (profiles/r02e_vgg16).
+// 3 (round 3): the tile THREE taps ahead is requested; a tap's wait leaves the requests of the previous tap in flight
+// (counted vmcnt: they are the youngest -- the halo pieces of a tap are issued before its weight pieces), so every request has
+// two taps to land.
+template <int WM, int WN, int MT, int PASSES, int NSLOT, int NWB = 2>
 __global__ __launch_bounds__(kDnThreads, (MT == 4 || PASSES == 3 ? 2 : 4)) void k_dense_mfma(const DenseParams p) {
     static_assert(WM * WN == 8, "8 waves");
+    static_assert(NWB == 2 || NWB == 3, "two or three weight buffers");
     constexpr int TH = WM * MT, BN = WN * 64, WT = BN * 128;  // WT: bytes of one tap's weight tile (one plane)
     constexpr int PL = PASSES == 3 ? 2 : 1;                   // operand planes
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* wbuf = smem;                 // [2 buffers][PL planes][WT]
-    unsigned char* xsb = wbuf + 2 * PL * WT;    // [2 buffers][PL planes][x_pieces * 1 KiB]   (8 halo pixels x 128 B per piece)
+    unsigned char* wbuf = smem;                 // [NWB buffers][PL planes][WT]
+    unsigned char* xsb = wbuf + NWB * PL * WT;  // [2 buffers][PL planes][x_pieces * 1 KiB]   (8 halo pixels x 128 B per piece)
     const uint32_t xbytes = (uint32_t)p.x_pieces * 1024u;
 
     uint32_t b = xcd_remap(blockIdx.x, p.nblocks);   // channel slice slowest: an XCD's L2 holds one W slice
@@ -201,6 +208,7 @@ __global__ __launch_bounds__(kDnThreads, (MT == 4 || PASSES == 3 ? 2 : 4)) void 
     const int n_steps = n_chunks * n_taps;
     stage_w(0, 0, 0);
     if (n_steps > 1) stage_w(n_taps > 1 ? 1 : 0, n_taps > 1 ? 0 : 1, 1);
+    if constexpr (NWB == 3) { if (n_steps > 2) stage_w(2 % n_taps, 2 / n_taps, 2); }
 #pragma unroll
     for (int j = 0; j < NSLOT; ++j)
         if (wave + 8 * j < p.x_pieces) stage_x(j, 0, 0);
@@ -213,6 +221,7 @@ __global__ __launch_bounds__(kDnThreads, (MT == 4 || PASSES == 3 ? 2 : 4)) void 
     // those DMAs fly.  Two weight buffers give a two-tap flight window because the operands of the
     // tap in progress live in registers.
     int wb = 0, xb = 0;
+    bool w_in_flight = false;   // NWB == 3: did the previous tap request a weight tile (wave-uniform)?
     for (int chunk = 0; chunk < n_chunks; ++chunk) {
         const bool more_chunks = chunk + 1 < n_chunks;
         const unsigned char* xs = xsb + (size_t)xb * PL * xbytes;
@@ -240,21 +249,33 @@ __global__ __launch_bounds__(kDnThreads, (MT == 4 || PASSES == 3 ? 2 : 4)) void 
             // NOT count a global_load_lds issued in the previous loop iteration when it lowers
             // __syncthreads() here (it emitted lgkmcnt(0) only: rare stale weight fragments at 12 544
             // workgroups), so the wait is explicit.
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (NWB == 3) {
+                // everything but the previous tap's weight pieces (the WN * PL youngest requests of this wave) has landed
+                if (w_in_flight) {
+                    if constexpr (WN * PL == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                    else if constexpr (WN * PL == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    else if constexpr (WN * PL == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             __syncthreads();
-            // the weight tile two taps ahead -> the buffer every wave has just finished reading
-            int tap2 = tap + 2, chunk2 = chunk;
-            if (tap2 >= n_taps) { tap2 -= n_taps; ++chunk2; }
-            if (tap2 >= n_taps) { tap2 -= n_taps; ++chunk2; }   // single-tap-row kernels (n_taps == 1 cannot occur)
-            if (chunk2 < n_chunks) stage_w(tap2, chunk2, wb);
             // a slice of the next chunk's halo; nothing on the last tap: its DMA would still be in flight
-            // when the next chunk's first fragments are read
+            // when the next chunk's first fragments are read.  Issued BEFORE the weight pieces (see NWB).
             if (more_chunks && tap + 1 < n_taps) {
 #pragma unroll
                 for (int j = 0; j < NSLOT; ++j) {   // slot j goes out with tap j / x_per_tap (wave-uniform)
                     if (j / p.x_per_tap == tap && wave + 8 * j < p.x_pieces) stage_x(j, chunk + 1, xb ^ 1);
                 }
             }
+            // the weight tile NWB taps ahead -> the buffer every wave has just finished reading
+            int tap2 = tap + NWB, chunk2 = chunk;
+            while (tap2 >= n_taps) { tap2 -= n_taps; ++chunk2; }
+            w_in_flight = chunk2 < n_chunks;
+            if (w_in_flight) stage_w(tap2, chunk2, wb);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
@@ -268,7 +289,7 @@ __global__ __launch_bounds__(kDnThreads, (MT == 4 || PASSES == 3 ? 2 : 4)) void 
                         }
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][j], xf[ks][i], acc[i][j], 0, 0, 0);
                     }
-            wb ^= 1;
+            wb = (NWB == 2) ? (wb ^ 1) : (wb == 2 ? 0 : wb + 1);
         }
         xb ^= 1;
     }
@@ -305,7 +326,7 @@ struct DenseCfg { int wm, wn, mt; };
 // instantiated tilings, widest first
 static const DenseCfg kDenseCfgs[] = {{2, 4, 4}, {4, 2, 4}, {4, 2, 2}, {4, 2, 1}, {8, 1, 2}, {8, 1, 1}};
 
-struct DenseGeom { DenseCfg cfg; int ih, iw, pieces, per_tap; size_t lds; int occ; };
+struct DenseGeom { DenseCfg cfg; int ih, iw, pieces, per_tap; size_t lds; int occ; int nwb; };
 
 static bool dense_cfg_geometry(const slfp_conv2d_desc& d, const DenseCfg& c, int planes, DenseGeom* g) {
     const int S = d.stride_h, th = c.wm * c.mt, taps = (int)(d.kh * d.kw);
@@ -314,9 +335,13 @@ static bool dense_cfg_geometry(const slfp_conv2d_desc& d, const DenseCfg& c, int
     g->iw = (kDnTW - 1) * S + (int)d.kw;
     g->pieces = (g->ih * g->iw + 7) / 8;
     g->per_tap = (int)ceil_div(ceil_div(g->pieces, 8), taps - 1);  // all slices issued before the last tap
+    g->nwb = 2;
     g->lds = (size_t)planes * (2 * (size_t)c.wn * 64 * 128 + 2 * (size_t)g->pieces * 1024);
     // MT 4 tilings hold 64 accumulator VGPRs + fragments: compiled for one workgroup per CU; the others for two
     g->occ = (c.mt == 4 || planes == 2) ? 1 : (g->lds <= 80 * 1024 ? 2 : 1);
+    // one workgroup per CU: nobody covers its DMA waits -> three weight buffers where they fit (single-plane kernels)
+    const size_t lds3 = g->lds + (size_t)planes * c.wn * 64 * 128;
+    if (g->occ == 1 && planes == 1 && taps >= 3 && lds3 <= 160 * 1024 && switches().dense_nwb != 2) { g->nwb = 3; g->lds = lds3; }
     return g->lds <= 160 * 1024 && ceil_div(g->pieces, 8) <= kMaxSlots;
 }
 
@@ -330,6 +355,7 @@ static bool dense_choose(const slfp_conv2d_desc& d, int planes, int64_t h_out, i
     for (const DenseCfg& c : kDenseCfgs) {
         DenseGeom g;
         if (!dense_cfg_geometry(d, c, planes, &g)) continue;
+        if (switches().dense_cfg && switches().dense_cfg == c.wm * 100 + c.wn * 10 + c.mt) { *best = g; return true; }   // sweep tool
         const int th = c.wm * c.mt, bn = c.wn * 64;
         const int64_t blocks = d.n * ceil_div(h_out, th) * ceil_div(w_out, kDnTW) * ceil_div(d.c_out, bn);
         const int64_t per_cu = ceil_div(blocks, 256);
@@ -367,8 +393,9 @@ size_t dense_mfma_workspace_bytes(const slfp_conv2d_desc& d, int passes) {
 }
 
 template <int WM, int WN, int MT, int PASSES, int NSLOT>
-static int launch_dense_tps(DenseParams& p, size_t lds, hipStream_t stream) {
+static int launch_dense_tps(DenseParams& p, size_t lds, hipStream_t stream, int nwb = 2) {
     auto fn = k_dense_mfma<WM, WN, MT, PASSES, NSLOT>;
+    if constexpr (PASSES == 1) { if (nwb == 3) fn = k_dense_mfma<WM, WN, MT, PASSES, NSLOT, 3>; }
     const int rc = raise_lds_limit(reinterpret_cast<const void*>(fn), 160 * 1024);  // once per (device, kernel)
     if (rc != SLFP_OK) return rc;
     hipLaunchKernelGGL(fn, dim3(p.nblocks), dim3(kDnThreads), lds, stream, p);
@@ -376,14 +403,14 @@ static int launch_dense_tps(DenseParams& p, size_t lds, hipStream_t stream) {
 }
 
 template <int WM, int WN, int MT, int PASSES>
-static int launch_dense_tp(DenseParams& p, size_t lds, hipStream_t stream) {
-    return ceil_div(p.x_pieces, 8) <= 3 ? launch_dense_tps<WM, WN, MT, PASSES, 3>(p, lds, stream)
-                                         : launch_dense_tps<WM, WN, MT, PASSES, kMaxSlots>(p, lds, stream);
+static int launch_dense_tp(DenseParams& p, size_t lds, hipStream_t stream, int nwb) {
+    return ceil_div(p.x_pieces, 8) <= 3 ? launch_dense_tps<WM, WN, MT, PASSES, 3>(p, lds, stream, nwb)
+                                         : launch_dense_tps<WM, WN, MT, PASSES, kMaxSlots>(p, lds, stream, nwb);
 }
 
 template <int WM, int WN, int MT>
-static int launch_dense_t(DenseParams& p, size_t lds, int planes, hipStream_t stream) {
-    return planes == 2 ? launch_dense_tp<WM, WN, MT, 3>(p, lds, stream) : launch_dense_tp<WM, WN, MT, 1>(p, lds, stream);
+static int launch_dense_t(DenseParams& p, size_t lds, int planes, hipStream_t stream, int nwb) {
+    return planes == 2 ? launch_dense_tp<WM, WN, MT, 3>(p, lds, stream, 2) : launch_dense_tp<WM, WN, MT, 1>(p, lds, stream, nwb);
 }
 
 int launch_dense_mfma(const slfp_conv2d_desc& d, const ConvPlan& plan, const float* x, const void* wblob,
@@ -423,12 +450,12 @@ int launch_dense_mfma(const slfp_conv2d_desc& d, const ConvPlan& plan, const flo
     if (nblocks > 0x7FFFFFFF) return fail(SLFP_ERR_UNSUPPORTED, "dense MFMA conv: grid too large");
     p.nblocks = (uint32_t)nblocks;
     switch (g.cfg.wm * 100 + g.cfg.wn * 10 + g.cfg.mt) {
-        case 244: return launch_dense_t<2, 4, 4>(p, g.lds, planes, stream);
-        case 424: return launch_dense_t<4, 2, 4>(p, g.lds, planes, stream);
-        case 422: return launch_dense_t<4, 2, 2>(p, g.lds, planes, stream);
-        case 421: return launch_dense_t<4, 2, 1>(p, g.lds, planes, stream);
-        case 812: return launch_dense_t<8, 1, 2>(p, g.lds, planes, stream);
-        default: return launch_dense_t<8, 1, 1>(p, g.lds, planes, stream);
+        case 244: return launch_dense_t<2, 4, 4>(p, g.lds, planes, stream, g.nwb);
+        case 424: return launch_dense_t<4, 2, 4>(p, g.lds, planes, stream, g.nwb);
+        case 422: return launch_dense_t<4, 2, 2>(p, g.lds, planes, stream, g.nwb);
+        case 421: return launch_dense_t<4, 2, 1>(p, g.lds, planes, stream, g.nwb);
+        case 812: return launch_dense_t<8, 1, 2>(p, g.lds, planes, stream, g.nwb);
+        default: return launch_dense_t<8, 1, 1>(p, g.lds, planes, stream, g.nwb);
     }
 }
 

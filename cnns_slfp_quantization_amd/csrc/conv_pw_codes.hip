@@ -193,6 +193,154 @@ __global__ __launch_bounds__(kPwcThreads) void k_pwc_stream(const PwcParams p) {
 }
 
 // ======================================================================================
+// k_pwc_slice: deep layers (K = 256 ... 1024).  W does not fit LDS, but a SLICE of output channels does: a workgroup keeps
+// the fragments of NTS channel tiles x all K resident (<= 128 KiB) and streams pixel units past them, as k_pwc_stream does.
+// Every slice reads all of X -- at 1 B per element that costs little (the float32 interface could not afford it: X four
+// to sixteen times through the encoder): the n_slices workgroups that work on the same pixels share an XCD (blocks b and
+// b + 8), so the re-reads are L2 hits, and a byte decodes in 1.5 VALU instructions.  What it removes is k_pwc_tiled's
+// per-workgroup W stream from L2 (512 KiB per 64 pixels: 4x the X + Y bytes of these layers) and its barrier per stage.
+// K is swept in chunks of KC k-steps with the accumulators of the slice's NTS tiles in registers; k order and MFMA shape
+// are those of the other pointwise kernels (bit-identical results).
+// ======================================================================================
+// The codes of the NEXT chunk -- or of the next unit's first chunk -- are always in flight under the current chunk's MFMAs.
+// Measured (round 3, batch 256, us per layer, k_pwc_stream / k_pwc_tiled -> this kernel): 256->256 @28 73 -> 56, 256->512 @14
+// 42 -> 34; but 512->512 @14 54 -> 54-64 and 1024->1024 @7 45 -> 66-76 (512 or 1024 threads): with W in LDS every MFMA needs a
+// 1 KiB fragment read, exactly the LDS rate of a CU, and the decode lookups come on top -- at K >= 512 the register-blocked
+// k_pwc_tiled (4 x 4 tiles per wave, W straight from L2) stays.  Used for K = 256 only (two workgroups per CU).
+constexpr int kSliceThreads = 512;
+template <int FMT, int NTS, bool YC>
+__global__ __launch_bounds__(kSliceThreads) void k_pwc_slice(const PwcParams p) {
+    constexpr int KC = 8;   // k-steps per chunk = 256 channels = 4 x 16-byte code loads per lane
+    static_assert(NTS % 4 == 0, "code output leaves in groups of 4 channel tiles");
+    __shared__ __attribute__((aligned(16))) uint32_t sdec[256];
+    __shared__ __attribute__((aligned(16))) unsigned char senc[YC ? kPwTab : 16];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    _Float16* wl = reinterpret_cast<_Float16*>(smem);
+    const int n_slices = p.n_tiles / NTS;
+    // blocks b and b + 8 share an XCD: the slices of one pixel range sit on consecutive (b / 8)
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int slice = q % n_slices;
+    const int rank = xcd + 8 * (q / n_slices);
+    const int n_ranks = 8 * ((int)(gridDim.x >> 3) / n_slices);
+    const int wfrags = NTS * p.KS;  // 1 KiB each
+    dec_fill<FMT, kDecF16D, kSliceThreads>(sdec);
+    if constexpr (YC) enc_fill<kSliceThreads>(reinterpret_cast<uint2*>(senc), p.enc);
+    {
+        const half8* src = reinterpret_cast<const half8*>(p.whi) + (size_t)slice * wfrags * 64;
+        for (int i = threadIdx.x; i < wfrags * 64; i += kSliceThreads) reinterpret_cast<half8*>(wl)[i] = src[i];
+    }
+    float* ep = reinterpret_cast<float*>(smem + (size_t)wfrags * 1024);   // [256 * bias/s1/s2 | post scale | post shift] of the slice
+    constexpr int NCH = NTS * 16;
+    const int n_lo = slice * NCH;
+    const bool has_vec = p.bias != nullptr || p.post.scale != nullptr;
+    if (has_vec) {
+        for (int i = threadIdx.x; i < NCH; i += kSliceThreads) {
+            const bool in = n_lo + i < p.N;
+            ep[i] = (p.bias && in) ? 256.f * ((p.bias[n_lo + i] / p.s1) / p.s2) : 0.f;
+            ep[NCH + i] = (p.post.scale && in) ? p.post.scale[n_lo + i] : 1.f;
+            ep[2 * NCH + i] = (p.post.scale && in) ? p.post.shift[n_lo + i] : 0.f;
+        }
+    }
+    __syncthreads();
+    const unsigned char* dtab = reinterpret_cast<const unsigned char*>(sdec);
+    const float r1 = p.enc.r1, lo = p.enc.lo, hi = p.enc.hi;
+
+    const int lane = threadIdx.x & 63;
+    const int col = lane & 15, kq = lane >> 4;
+    const int64_t n_groups = (p.M + 15) >> 4;
+    const int64_t stride = (int64_t)n_ranks * (kSliceThreads / 64);
+    const int n_chunks = p.KS / KC;
+
+    u32x4c v[KC / 2];
+    {
+        const int64_t g0 = (int64_t)rank * (kSliceThreads / 64) + (threadIdx.x >> 6);
+        const int64_t m0 = (g0 < n_groups ? g0 : n_groups - 1) * 16 + col;
+        const uint8_t* x0 = p.x + xc_row_offset(p, m0 < p.M ? m0 : p.M - 1) + kq * 16;
+#pragma unroll
+        for (int c2 = 0; c2 < KC / 2; ++c2) v[c2] = *reinterpret_cast<const u32x4c*>(x0 + c2 * 64);
+    }
+    for (int64_t g = (int64_t)rank * (kSliceThreads / 64) + (threadIdx.x >> 6); g < n_groups; g += stride) {
+        const int64_t m = g * 16 + col;
+        const bool live = m < p.M;
+        const uint8_t* xr = p.x + xc_row_offset(p, live ? m : p.M - 1) + kq * 16;
+        // first chunk of the next unit of this wave (its own unit again on the last round: L1 hits, unused)
+        const int64_t gn = g + stride < n_groups ? g + stride : g;
+        const int64_t mn = gn * 16 + col;
+        const uint8_t* xrn = p.x + xc_row_offset(p, mn < p.M ? mn : p.M - 1) + kq * 16;
+        floatx4 acc[NTS];
+#pragma unroll
+        for (int j = 0; j < NTS; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+        for (int kc = 0; kc < n_chunks; ++kc) {
+            half8 xh[KC];
+#pragma unroll
+            for (int c2 = 0; c2 < KC / 2; ++c2) {
+                uint32_t a0 = v[c2][0], a1 = v[c2][1], a2 = v[c2][2], a3 = v[c2][3];
+                rows_transpose4(a0, a1, a2, a3);
+                xh[2 * c2] = dec_frag(a0, a1, dtab);
+                xh[2 * c2 + 1] = dec_frag(a2, a3, dtab);
+            }
+            {   // the next chunk's codes -- after the last chunk: the next unit's first -- fly during this chunk's MFMAs
+                const uint8_t* nx = kc + 1 < n_chunks ? xr + (kc + 1) * (KC * 32) : xrn;
+#pragma unroll
+                for (int c2 = 0; c2 < KC / 2; ++c2) v[c2] = *reinterpret_cast<const u32x4c*>(nx + c2 * 64);
+            }
+            const _Float16* wk = wl + (size_t)(kc * KC) * 512 + lane * 8;
+#pragma unroll
+            for (int j = 0; j < NTS; ++j) {
+#pragma unroll
+                for (int ks = 0; ks < KC; ++ks) {
+                    const half8 wh = *reinterpret_cast<const half8*>(wk + ((size_t)j * p.KS + ks) * 512);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[ks], acc[j], 0, 0, 0);
+                }
+            }
+        }
+        auto finish = [&](int j) {
+            const int n = j * 16 + kq * 4;   // channel inside the slice
+            float4 r;
+            if (has_vec) {
+                const float4 bq = *reinterpret_cast<const float4*>(ep + n);
+                const float4 sc = *reinterpret_cast<const float4*>(ep + NCH + n);
+                const float4 sh = *reinterpret_cast<const float4*>(ep + 2 * NCH + n);
+                r = epilogue(acc[j], bq, p.s1x, p.s2);
+                if (p.post.scale) {
+                    r.x = __builtin_fmaf(r.x, sc.x, sh.x); r.y = __builtin_fmaf(r.y, sc.y, sh.y);
+                    r.z = __builtin_fmaf(r.z, sc.z, sh.z); r.w = __builtin_fmaf(r.w, sc.w, sh.w);
+                }
+            } else {
+                r = epilogue(acc[j], make_float4(0.f, 0.f, 0.f, 0.f), p.s1x, p.s2);
+            }
+            if constexpr (!YC) {
+                if (p.post.relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+            }
+            return r;
+        };
+        if constexpr (YC) {
+            uint8_t* yr = reinterpret_cast<uint8_t*>(p.y) + (size_t)m * p.N + n_lo;
+#pragma unroll
+            for (int j0 = 0; j0 < NTS; j0 += 4) {
+                uint32_t c[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 r = finish(j0 + j);
+                    if (p.sgn) c[j] = code_sign4(enc4_code<false>(r, r1, lo, hi, senc), r, p.fmt_out);
+                    else c[j] = enc4_code_relu(r, r1, lo, hi, senc);
+                }
+                rows_transpose4(c[0], c[1], c[2], c[3]);
+                const int n = (j0 + kq) * 16;
+                if (live && n_lo + n < p.N) *reinterpret_cast<u32x4c*>(yr + n) = u32x4c{c[0], c[1], c[2], c[3]};
+            }
+        } else {
+            float* yr = reinterpret_cast<float*>(p.y) + (size_t)m * p.N + n_lo + kq * 4;
+#pragma unroll
+            for (int j = 0; j < NTS; ++j) {
+                const float4 r = finish(j);
+                if (live && n_lo + j * 16 + kq * 4 < p.N) *reinterpret_cast<float4*>(yr + j * 16) = r;
+            }
+        }
+    }
+}
+
+// ======================================================================================
 // k_pwc_tiled: codes -> swizzled fp16 LDS tile (decoded once), W fragments straight from L2.
 // ======================================================================================
 // K a multiple of 64; NT = 4 channel tiles per wave.  STG-style float32 epilogue as in conv_pw.hip's k_pw_tiled.
@@ -422,8 +570,42 @@ static int launch_pwc_tiled(PwcParams& p, bool y_codes, hipStream_t stream) {
     return check_launch("slfp pointwise (codes, tiled) kernel");
 }
 
+// slice kernel: K a multiple of 256, the slice's W (NTS tiles x K) <= 128 KiB, N a multiple of 16 * NTS
+static int pwc_slice_nts(const PwcParams& p) {
+    if (p.K != 256 || !switches().pwc_slice) return 0;   // see k_pwc_slice: deeper layers stay on k_pwc_tiled
+    for (int nts : {8, 4}) {
+        if ((size_t)nts * 16 * p.K * 2 <= 128 * 1024 && p.N % (nts * 16) == 0 && p.n_tiles % nts == 0) return nts;
+    }
+    return 0;
+}
+
+template <int FMT, int NTS>
+static int launch_pwc_slice(PwcParams& p, bool y_codes, hipStream_t stream) {
+    const size_t lds = (size_t)NTS * p.KS * 1024 + (size_t)3 * NTS * 16 * sizeof(float);
+    auto fn = y_codes ? k_pwc_slice<FMT, NTS, true> : k_pwc_slice<FMT, NTS, false>;
+    int rc = raise_lds_limit(reinterpret_cast<const void*>(fn), lds);
+    if (rc != SLFP_OK) return rc;
+    int per_cu = resident_blocks_per_cu(reinterpret_cast<const void*>(fn), kSliceThreads, lds);
+    per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
+    const int n_slices = p.n_tiles / NTS;
+    // grid = 8 (XCDs) x n_slices x ranks-per-XCD: as many whole (slice set) groups as fit the device
+    const int64_t slots = (int64_t)device_cu_count() * per_cu;
+    int64_t groups = slots / (8 * n_slices);
+    if (groups < 1) groups = 1;
+    const int64_t units = (p.M + 15) / 16;
+    const int64_t need = ceil_div(units, (int64_t)8 * (kSliceThreads / 64));   // ranks needed, in multiples of 8 (one per XCD)
+    if (groups > need) groups = need < 1 ? 1 : need;
+    const int64_t grid = groups * 8 * n_slices;
+    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(kSliceThreads), lds, stream, p);
+    return check_launch("slfp pointwise (codes, slice) kernel");
+}
+
 template <int FMT>
 static int launch_pwc_fmt(PwcParams& p, const ConvPlan& plan, bool y_codes, hipStream_t stream) {
+    if (const int nts = pwc_slice_nts(p)) {
+        if (nts == 8) return launch_pwc_slice<FMT, 8>(p, y_codes, stream);
+        return launch_pwc_slice<FMT, 4>(p, y_codes, stream);
+    }
     if (pwc_stream_fits(plan)) {
         switch (p.K / 32) {
             case 1: return launch_pwc_stream<FMT, 1, false>(p, y_codes, stream);
