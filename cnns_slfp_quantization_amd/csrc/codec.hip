@@ -72,6 +72,7 @@ static Switches read_switches() {
     w.stem_old = std::getenv("SLFP_STEM_OLD") != nullptr;
     w.stem_mx = std::getenv("SLFP_STEM_MX") != nullptr;
     w.pwc_slice = std::getenv("SLFP_PWC_NOSLICE") == nullptr;
+    w.dense_generic = std::getenv("SLFP_DENSE_GENERIC") != nullptr;
     e = std::getenv("SLFP_DENSE_CFG");
     w.dense_cfg = e ? atoi(e) : 0;
     e = std::getenv("SLFP_DENSE_NWB");

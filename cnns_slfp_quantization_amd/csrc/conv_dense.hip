@@ -321,6 +321,181 @@ __global__ __launch_bounds__(kDnThreads, (MT == 4 || PASSES == 3 ? 2 : 4)) void 
     }
 }
 
+// ======================================================================================
+// k_dense3x3: k_dense_mfma specialised for 3x3, stride 1, single pass (every VGG-16 layer, 13 of ResNet-50's 16 3x3 layers,
+// SqueezeNet's expand3x3) -- round 3.  The general kernel derives every fragment address inside the tap loop (tap -> (kh, kw)
+// by division, halo row, XOR swizzle: 60-100 VALU instructions per tap and wave around 16-32 MFMAs, profiles/r02e_vgg16:
+// valu_insts_per_wave 1475-4315, mfma_busy 0.32-0.50) and is VALU-issue-bound on them.  Here the 9 taps are unrolled: a
+// lane's fragment offsets depend on the tap only through (halo row i + kh, kw), so the (MT + 2) x 3 swizzled offsets are
+// computed ONCE per workgroup; per tap what is left is one add per fragment (the halo buffer of the chunk) and one XOR for
+// the second k-step (the swizzle moves bit 6 with it).  Same staging, same waits, same MFMA order: bit-identical results.
+// ======================================================================================
+template <int WM, int WN, int MT, int NSLOT, int NWB>
+__global__ __launch_bounds__(kDnThreads, (MT == 4 ? 2 : 4)) void k_dense3x3(const DenseParams p) {
+    static_assert(WM * WN == 8, "8 waves");
+    constexpr int TH = WM * MT, BN = WN * 64, WT = BN * 128;
+    constexpr int IW = kDnTW + 2;   // halo width of a 16-column tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* wbuf = smem;                 // [NWB buffers][WT]
+    unsigned char* xsb = wbuf + NWB * WT;       // [2 buffers][x_pieces * 1 KiB]
+    const uint32_t xbytes = (uint32_t)p.x_pieces * 1024u;
+
+    uint32_t b = xcd_remap(blockIdx.x, p.nblocks);
+    const int tw = b % p.tiles_w; b /= p.tiles_w;
+    const int th = b % p.tiles_h; b /= p.tiles_h;
+    const int n = b % p.N;
+    const int nb = b / p.N;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int col = lane & 15, kq = lane >> 4;
+    const int h_in0 = th * TH - p.ph, w_in0 = tw * kDnTW - p.pw;
+
+    // halo pieces: as k_dense_mfma
+    const unsigned char* xen = reinterpret_cast<const unsigned char*>(p.xe) + (size_t)n * p.H * p.W * p.Cp * 2;
+    const unsigned char* zp = p.zero_page + (lane & 7) * 16;
+    constexpr uint32_t kPad = 0xFFFFFFFFu;
+    uint32_t xoff[NSLOT];
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j) {
+        const int pc = wave + 8 * j;
+        const int pix = pc * 8 + (lane >> 3);
+        const int ih = pix / IW, iw = pix - ih * IW;
+        const int gh = h_in0 + ih, gw = w_in0 + iw;
+        const int c16 = (lane & 7) ^ (((pix >> 1) & 3) << 1);
+        const bool inb = pc < p.x_pieces && pix < p.n_pix && (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W;
+        xoff[j] = inb ? (uint32_t)((gh * p.W + gw) * p.Cp) * 2u + (uint32_t)c16 * 16u : kPad;
+    }
+    auto stage_x = [&](int j, int chunk, int buf) {
+        const int pc = wave + 8 * j;
+        const bool live = xoff[j] != kPad;
+        const unsigned char* src = live ? xen + (xoff[j] + (uint32_t)chunk * 128u) : zp;
+        glds16(src, xsb + (size_t)buf * xbytes + (size_t)pc * 1024);
+    };
+    const int nt0 = nb * (BN / 16);
+    const unsigned char* wsrc[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int pc = wave * WN + j;
+        int nt = nt0 + (pc >> 1);
+        nt = nt < p.n_tiles ? nt : p.n_tiles - 1;
+        wsrc[j] = reinterpret_cast<const unsigned char*>(p.w) + ((size_t)nt * p.KS + (pc & 1)) * 1024 + (size_t)lane * 16;
+    }
+    const size_t w_tap_stride = (size_t)p.n_tiles * p.KS * 1024;
+    auto stage_w = [&](int tap, int chunk, int buf) {
+        const size_t o = (size_t)tap * w_tap_stride + (size_t)chunk * 2048;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) glds16(wsrc[j] + o, wbuf + (size_t)buf * WT + (size_t)(wave * WN + j) * 1024);
+    };
+
+    // this lane's fragment offsets inside a halo buffer, k-step 0: halo row (wm * MT + r), column col + kw
+    uint32_t xo[MT + 2][3];
+#pragma unroll
+    for (int r = 0; r < MT + 2; ++r)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) xo[r][kw] = dn_x_off((wm * MT + r) * IW + col + kw, kq);
+    const uint32_t wlane = (uint32_t)(wn * 4) * 2048u + (uint32_t)lane * 16u;
+
+    floatx4 acc[MT][4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    const int n_chunks = p.KS >> 1;
+    constexpr int n_taps = 9;
+    const int n_steps = n_chunks * n_taps;
+    stage_w(0, 0, 0);
+    stage_w(1, 0, 1);
+    if constexpr (NWB == 3) stage_w(2, 0, 2);
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j)
+        if (wave + 8 * j < p.x_pieces) stage_x(j, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    (void)n_steps;
+
+    int wb = 0, xb = 0;
+    bool w_in_flight = false;
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+        const bool more_chunks = chunk + 1 < n_chunks;
+        const uint32_t xs_off = (uint32_t)(NWB * WT) + (uint32_t)xb * xbytes;   // byte offset of this chunk's halo buffer in smem
+#pragma unroll
+        for (int tap = 0; tap < n_taps; ++tap) {
+            const int kh = tap / 3, kw = tap % 3;   // compile-time after unrolling
+            const unsigned char* wt = wbuf + (size_t)wb * WT + wlane;
+            half8 wf[2][4], xf[2][MT];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wf[ks][j] = *reinterpret_cast<const half8*>(wt + j * 2048 + ks * 1024);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                // the add stays HERE (hipcc otherwise hoists the 9 x MT x 2 addresses of a chunk to its top: 40-70 live VGPRs, spills)
+                uint32_t o0 = xs_off + xo[i + kh][kw];
+                asm volatile("" : "+v"(o0));
+                xf[0][i] = *reinterpret_cast<const half8*>(smem + o0);
+                xf[1][i] = *reinterpret_cast<const half8*>(smem + (o0 ^ 64u));   // k-step 1: chunk bit 2 -> byte-offset bit 6
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (NWB == 3) {
+                if (w_in_flight) {
+                    if constexpr (WN == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                    else if constexpr (WN == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+            if (more_chunks && tap < NSLOT && tap + 1 < n_taps) {   // slot `tap` of the next chunk's halo (x_per_tap == 1)
+                if (wave + 8 * tap < p.x_pieces) stage_x(tap, chunk + 1, xb ^ 1);
+            }
+            int tap2 = tap + NWB, chunk2 = chunk;
+            if (tap2 >= n_taps) { tap2 -= n_taps; ++chunk2; }
+            w_in_flight = chunk2 < n_chunks;
+            if (w_in_flight) stage_w(tap2, chunk2, wb);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][j], xf[ks][i], acc[i][j], 0, 0, 0);
+            // the next tap's fragment reads stay behind this tap's MFMAs (hoisted, two taps' fragments are live at once: spills)
+            __builtin_amdgcn_sched_barrier(0);
+            wb = (NWB == 2) ? (wb ^ 1) : (wb == 2 ? 0 : wb + 1);
+        }
+        xb ^= 1;
+    }
+
+    const int gow = tw * kDnTW + col;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ch = (nt0 + wn * 4 + j) * 16 + kq * 4;
+        if (ch >= p.O) continue;
+        float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias) {
+            const float4 bb = *reinterpret_cast<const float4*>(p.bias + ch);
+            bq = make_float4(256.f * ((bb.x / p.s1) / p.s2), 256.f * ((bb.y / p.s1) / p.s2),
+                             256.f * ((bb.z / p.s1) / p.s2), 256.f * ((bb.w / p.s1) / p.s2));
+        }
+        const PostVec pv = post_load(p.post, ch);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int goh = th * TH + wm * MT + i;
+            if (goh >= p.Ho || gow >= p.Wo) continue;
+            float4 r;
+            r.x = ((acc[i][j][0] + bq.x) * p.s1x) * p.s2;
+            r.y = ((acc[i][j][1] + bq.y) * p.s1x) * p.s2;
+            r.z = ((acc[i][j][2] + bq.z) * p.s1x) * p.s2;
+            r.w = ((acc[i][j][3] + bq.w) * p.s1x) * p.s2;
+            st_stream4<SLFP_NT_DENSE>(p.y + (((size_t)n * p.Ho + goh) * p.Wo + gow) * p.O + ch, post_apply_v(r, p.post, pv));
+        }
+    }
+}
+
 // ---- host side: pick the tiling ----------------------------------------------------------
 struct DenseCfg { int wm, wn, mt; };
 // instantiated tilings, widest first
@@ -360,6 +535,13 @@ static bool dense_choose(const slfp_conv2d_desc& d, int planes, int64_t h_out, i
         const int64_t blocks = d.n * ceil_div(h_out, th) * ceil_div(w_out, kDnTW) * ceil_div(d.c_out, bn);
         const int64_t per_cu = ceil_div(blocks, 256);
         double f = c.mt == 4 ? (c.wn == 4 ? 1.12 : 1.15) : (c.mt == 2 && c.wn == 2 ? 1.0 : 1.5);
+        // round 3: 3x3 stride-1 single-plane layers run the unrolled k_dense3x3 on the MT = 4 / MT = 1 tilings: measured per
+        // VGG-16 layer (batch 128, profiles/dense_cfg_sweep3.sh) {4,2,4} 500 / 830 / 324 / 580 / 155 us against the general
+        // kernel's {4,2,2} 513 / 845 / 367 / 683 / 182; 64 -> 64 @224: {8,1,1} 1509 against 1628
+        if (planes == 1 && d.kh == 3 && d.kw == 3 && d.stride_h == 1 && !switches().dense_generic) {
+            if (c.mt == 4 && c.wn == 2) f = 0.92;
+            else if (c.mt == 1 && c.wm == 8) f = 1.2;
+        }
         if (c.mt != 4 && g.occ < 2) f *= 1.15;   // built for two workgroups per CU but LDS only fits one
         if (per_cu < g.occ) f *= 1.3;            // too few workgroups to pair up
         const double cost = (double)per_cu * th * bn * f;
@@ -396,6 +578,13 @@ template <int WM, int WN, int MT, int PASSES, int NSLOT>
 static int launch_dense_tps(DenseParams& p, size_t lds, hipStream_t stream, int nwb = 2) {
     auto fn = k_dense_mfma<WM, WN, MT, PASSES, NSLOT>;
     if constexpr (PASSES == 1) { if (nwb == 3) fn = k_dense_mfma<WM, WN, MT, PASSES, NSLOT, 3>; }
+    if constexpr (PASSES == 1 && NSLOT <= 8 && MT != 2) {
+        // 3x3 stride 1 with one halo slice per tap: the unrolled kernel (same staging plan, same results).  Not for the MT = 2
+        // tilings: two workgroups per CU cap them at 128 registers and the unrolled body spills there (measured slower).
+        if (p.KH == 3 && p.KW == 3 && p.S == 1 && p.x_per_tap == 1 && ceil_div(p.x_pieces, 8) <= NSLOT && !switches().dense_generic) {
+            fn = nwb == 3 ? k_dense3x3<WM, WN, MT, NSLOT, 3> : k_dense3x3<WM, WN, MT, NSLOT, 2>;
+        }
+    }
     const int rc = raise_lds_limit(reinterpret_cast<const void*>(fn), 160 * 1024);  // once per (device, kernel)
     if (rc != SLFP_OK) return rc;
     hipLaunchKernelGGL(fn, dim3(p.nblocks), dim3(kDnThreads), lds, stream, p);
@@ -404,8 +593,10 @@ static int launch_dense_tps(DenseParams& p, size_t lds, hipStream_t stream, int 
 
 template <int WM, int WN, int MT, int PASSES>
 static int launch_dense_tp(DenseParams& p, size_t lds, hipStream_t stream, int nwb) {
-    return ceil_div(p.x_pieces, 8) <= 3 ? launch_dense_tps<WM, WN, MT, PASSES, 3>(p, lds, stream, nwb)
-                                         : launch_dense_tps<WM, WN, MT, PASSES, kMaxSlots>(p, lds, stream, nwb);
+    const int slots = (int)ceil_div(p.x_pieces, 8);
+    if (slots <= 3) return launch_dense_tps<WM, WN, MT, PASSES, 3>(p, lds, stream, nwb);
+    if (slots <= 6 && p.KH == 3 && p.KW == 3 && p.S == 1) return launch_dense_tps<WM, WN, MT, PASSES, 6>(p, lds, stream, nwb);
+    return launch_dense_tps<WM, WN, MT, PASSES, kMaxSlots>(p, lds, stream, nwb);
 }
 
 template <int WM, int WN, int MT>

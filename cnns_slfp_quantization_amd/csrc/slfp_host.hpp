@@ -55,6 +55,7 @@ struct Switches {
     bool stem_mx;             // SLFP_STEM_MX: the float32 MFMA stem also for float32 output (default: code output only)
     bool stem_old;            // SLFP_STEM_OLD: the MobileNetV1 stem on the vector ALU (k_stem_fixed) instead of the float32 MFMA kernel
     bool pwc_slice;           // SLFP_PWC_NOSLICE unsets it: deep code-path pointwise layers on k_pwc_tiled / k_pwc_stream instead of k_pwc_slice
+    bool dense_generic;       // SLFP_DENSE_GENERIC: 3x3 stride-1 layers on the general k_dense_mfma instead of the unrolled k_dense3x3
     int dense_cfg;            // SLFP_DENSE_CFG=<wm><wn><mt> (e.g. 244): force a dense k x k tiling where it fits (sweeps); 0 = cost model
     int dense_nwb;            // SLFP_DENSE_NWB=2: keep two weight buffers everywhere (A/B of the three-buffer pipeline)
     int pw_stream_max_kb;     // SLFP_PW_STREAM_MAX_KB: largest W (KiB, fp16) the LDS-resident stream kernel takes (default 128)
