@@ -70,7 +70,6 @@ static Switches read_switches() {
     e = std::getenv("SLFP_DW_NT_MIN_MB");
     w.dw_nt_min_mb = e ? atoll(e) : 120;
     w.stem_old = std::getenv("SLFP_STEM_OLD") != nullptr;
-    w.stem_mx = std::getenv("SLFP_STEM_MX") != nullptr;
     w.pwc_slice = std::getenv("SLFP_PWC_NOSLICE") == nullptr;
     w.dense_generic = std::getenv("SLFP_DENSE_GENERIC") != nullptr;
     e = std::getenv("SLFP_DENSE_CFG");

@@ -493,30 +493,43 @@ __global__ __launch_bounds__(256) void k_stem_mx(const float* __restrict__ x, co
     }
     __syncthreads();   // tables visible
 
-    {   // load + quantize the halo tile: rows are contiguous in NHWC, one dword per lane (as k_stem_fixed<.., TAB>)
+    {   // load + quantize the halo tile.  Rows are contiguous in NHWC (99 floats of a 672-float image row, starting 3 floats
+        // before a multiple of 32 pixels): each lane loads 16 ALIGNED bytes of the 100-float superset that starts one float
+        // earlier -- 4 loads per thread instead of 13 dword loads (the stem kernels took ~120 us whatever they computed or
+        // stored: the vector memory pipe was busy with 650 k dword-load instructions per launch, profiles/r03c).
+        // Needs W * C to be a multiple of 4 floats (the launcher checks): a float4 is then wholly inside or outside its row.
+        constexpr int Q = (IWC + 1 + 3) / 4;            // float4 per tile row (25)
+        constexpr int N4 = IH * Q, U4 = (N4 + 255) / 256;
         const float* xn = x + (size_t)n * p.H * p.W * C;
-        const int j_lo = -w_in0 * C, j_hi = (p.W - w_in0) * C;
+        const int rowf = p.W * C;                        // floats per image row
+        const int s0 = w_in0 * C - 1;                    // superset start inside the image row (a multiple of 4, or -4)
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xn), 0, (uint32_t)p.H * p.W * C * 4u, 0x00020000);
-        uint32_t vo[U];
-        float v[U];
+        uint32_t vo[U4];
+        typedef float f32x4l __attribute__((ext_vector_type(4)));
+        f32x4l v[U4];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+        for (int u = 0; u < U4; ++u) {
             const int idx = threadIdx.x + u * 256;
-            const int ih = idx / IWC, j = idx - ih * IWC;  // compile-time divisor
-            const int gh = h_in0 + ih;
-            const bool ok = idx < N_IN && (unsigned)gh < (unsigned)p.H && j >= j_lo && j < j_hi;
-            vo[u] = ok ? (uint32_t)((gh * p.W + w_in0) * C + j) * 4u : 0xFFFFFFF0u;
+            const int ih = idx / Q, q = idx - ih * Q;    // compile-time divisor
+            const int gh = h_in0 + ih, f0 = s0 + 4 * q;
+            const bool ok = idx < N4 && (unsigned)gh < (unsigned)p.H && f0 >= 0 && f0 < rowf;
+            vo[u] = ok ? (uint32_t)(gh * rowf + f0) * 4u : 0xFFFFFFF0u;
             asm volatile("" : "+v"(vo[u]));
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vo[u], 0, 0));
+        for (int u = 0; u < U4; ++u) v[u] = __builtin_bit_cast(f32x4l, __builtin_amdgcn_raw_buffer_load_b128(rs, vo[u], 0, 0));
         const unsigned char* tb = reinterpret_cast<const unsigned char*>(sT);
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+        for (int u = 0; u < U4; ++u) {
             const int idx = threadIdx.x + u * 256;
-            float q = enc_f32(v[u], p.enc.r1, p.enc.lo, p.enc.hi, tb);
-            q = v[u] != v[u] ? __uint_as_float(kBitsQNaN) : q;   // NaN in -> NaN out
-            if (idx < N_IN) tile[idx] = q;
+            const int ih = idx / Q, q = idx - ih * Q;
+            const float4 xv = make_float4(v[u][0], v[u][1], v[u][2], v[u][3]);
+            const float4 qv = enc4_f32(xv, p.enc.r1, p.enc.lo, p.enc.hi, tb);   // NaN in -> NaN out
+            const float qs[4] = {qv.x, qv.y, qv.z, qv.w};
+            float* trow = tile + ih * IWC + 4 * q - 1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (idx < N4 && 4 * q + e >= 1 && 4 * q + e - 1 < IWC) trow[e] = qs[e];
         }
     }
     __syncthreads();
@@ -637,11 +650,11 @@ static int try_launch_stem(const slfp_conv2d_desc& d, const ConvPlan& plan, cons
             constexpr int TH = 16;
             p.tiles_h = (int)ceil_div(p.Ho, TH);
             p.nblocks = (uint32_t)((int64_t)p.N * p.tiles_h * p.tiles_w);
-            // float32 matrix-core stem (k_stem_mx): measured (round 3, same box) 121.6 vs 131.4 us with code output, 121.4 vs
-            // 118.9 us with float32 output (both HBM-side bound there) -> default for code output only; SLFP_STEM_MX forces it
-            // for float32 output too, SLFP_STEM_OLD keeps the vector kernel everywhere.  Bit-identical either way.
-            const bool mx = !switches().stem_old;
-            if (mx && switches().stem_mx && !(io && io->y_codes)) {
+            // float32 matrix-core stem (k_stem_mx) with aligned 16-byte halo loads: measured (round 3, same box, us per launch at
+            // batch 256) 111.8 vs 123.0 for the vector kernel with float32 output, 117.8 vs 131.4 with code output ->
+            // the default for both; SLFP_STEM_OLD keeps the vector kernel.  Bit-identical either way (tests/test_gpu_parity.py).
+            const bool mx = !switches().stem_old && (p.W * C) % 4 == 0;   // k_stem_mx loads aligned float4 pieces of the image rows
+            if (mx && !(io && io->y_codes)) {
                 hipLaunchKernelGGL((k_stem_mx<false>), dim3(p.nblocks), dim3(256), 0, stream, x, wq_hwio, bias, y, p);
                 return check_launch("slfp stem conv kernel (3x3x3 s2 -> 32, float32 MFMA)");
             }

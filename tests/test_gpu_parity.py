@@ -1319,7 +1319,7 @@ def test_conv2d_Q_raw_bias_forward_against_reference_fixture(lib, dev):
 
 def test_stem_float32_mfma_is_bit_identical_to_the_vector_kernel(lib, dev):
     """Round 3: the MobileNetV1 stem (nets_imgnet/mobilenetv1.py:44) can run its 27-tap float32 FMA chain on
-    v_mfma_f32_16x16x4_f32 (csrc/conv_direct.hip: k_stem_mx; the default when the output leaves as 1-byte codes).  The
+    v_mfma_f32_16x16x4_f32 (csrc/conv_direct.hip: k_stem_mx, the default since round 3; SLFP_STEM_OLD = the vector kernel).  The
     instruction multiplies float32 exactly and accumulates in k order, so the result must equal the vector kernel's bit for
     bit -- with and without the fused BatchNorm + ReLU, full and ragged tiles, NaN inputs -- and sit within float32
     round-off of the oracle."""
@@ -1344,10 +1344,11 @@ def test_stem_float32_mfma_is_bit_identical_to_the_vector_kernel(lib, dev):
             xn.view(-1)[7::1001] = float("nan")
             outs = {}
             for mx in (True, False):
-                os.environ.pop("SLFP_STEM_MX", None)
                 os.environ.pop("SLFP_STEM_OLD", None)
-                os.environ["SLFP_STEM_MX" if mx else "SLFP_STEM_OLD"] = "1"
+                if not mx:
+                    os.environ["SLFP_STEM_OLD"] = "1"
                 L.slfp_debug_reload_switches()
+                assert L.slfp_conv2d_kernel_name(ctypes.byref(d)).decode() == "stem_nhwc"
                 for post in (False, True):
                     for xin, tag in ((x, "clean"), (xn, "nan")):
                         y = torch.empty((n, ho, wo, 32), device=dev)
@@ -1362,5 +1363,4 @@ def test_stem_float32_mfma_is_bit_identical_to_the_vector_kernel(lib, dev):
             assert np.abs(y - ref).max() <= 1e-5 * np.abs(ref).max()
     finally:
         os.environ.pop("SLFP_STEM_OLD", None)
-        os.environ.pop("SLFP_STEM_MX", None)
         L.slfp_debug_reload_switches()
