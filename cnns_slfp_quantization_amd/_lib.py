@@ -25,6 +25,7 @@ SYMBOLS = (
     "slfp_nchw_to_nhwc_f32", "slfp_nhwc_to_nchw_f32", "slfp_debug_div_mismatches",
     "slfp_debug_enc_mismatches", "slfp_enc_table_ok", "slfp_dwpw_supported", "slfp_dwpw_fwd",
     "slfp_conv2d_codes_supported", "slfp_conv2d_fwd_codes", "slfp_debug_code_mismatches", "slfp_debug_reload_switches",
+    "slfp_debug_enc_hl_mismatches",
 )
 
 
@@ -104,6 +105,7 @@ def load():
         "slfp_conv2d_fwd_codes": (ci, [dp, ctypes.POINTER(ConvIo), vp, vp, vp, vp, vp, ci, vp, vp]),
         "slfp_debug_code_mismatches": (ci, [cf, ci, vp, vp]),
         "slfp_debug_reload_switches": (None, []),
+        "slfp_debug_enc_hl_mismatches": (ci, [cf, ci, vp, vp]),
     }
     assert set(sigs) == set(SYMBOLS)
     for name, (res, args) in sigs.items():

@@ -64,6 +64,26 @@ __device__ __forceinline__ half8 enc_frag_nan(const float4 a, const float4 b, co
     return __builtin_bit_cast(half8, u32x4{pa.x, pa.y, pb.x, pb.y});
 }
 
+// the same for the three-pass mode: hi and lo fragments from the two tables (NaN: patched by the caller's cold branch)
+__device__ __forceinline__ void enc_frag_hl(const float4 a, const float4 b, const EncArgs& e, const unsigned char* tb,
+                                            const unsigned char* tl, half8& h, half8& l) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    uint32_t h0, h1, h2, h3, l0, l1, l2, l3;
+    enc2_f16_hl(a.x, a.y, e.r1, e.lo, e.hi, tb, tl, h0, l0);
+    enc2_f16_hl(a.z, a.w, e.r1, e.lo, e.hi, tb, tl, h1, l1);
+    enc2_f16_hl(b.x, b.y, e.r1, e.lo, e.hi, tb, tl, h2, l2);
+    enc2_f16_hl(b.z, b.w, e.r1, e.lo, e.hi, tb, tl, h3, l3);
+    h = __builtin_bit_cast(half8, u32x4{h0, h1, h2, h3});
+    l = __builtin_bit_cast(half8, u32x4{l0, l1, l2, l3});
+}
+// NaN inputs of a fragment -> NaN in the hi plane, 0 in the lo plane (what (_Float16)NaN and NaN - NaN... give is NaN either way)
+__device__ __forceinline__ void frag_patch_nan(const float4 a, const float4 b, half8& h) {
+    const float xs[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (xs[i] != xs[i]) h[i] = (_Float16)__uint_as_float(0x7FC00000u);
+}
+
 // element offset of input pixel row m (strided 1x1 reads pixel (oh*S, ow*S))
 __device__ __forceinline__ size_t x_row_offset(const PwParams& p, int64_t m) {
     if (p.S == 1) return (size_t)m * p.K;
@@ -106,12 +126,13 @@ constexpr int kStreamThreads = 512;
 // 16 channels): HBM writes of 64-byte pieces run at about half the rate (profiles/micro/bw_patterns.hip).
 template <int FMT, int PASSES, int KS, bool KFULL, bool A8 = false, bool TAB = false, bool STG = false>
 __global__ __launch_bounds__(kStreamThreads) void k_pw_stream(const PwParams p) {
-    static_assert(!TAB || PASSES == 1, "the table form produces the single fp16 operand");
     static_assert(!STG || (TAB && !A8), "staged stores: table kernels with 16-byte channel alignment");
     constexpr int TABB = TAB ? kPwTab : 64;
+    constexpr int TABL = (TAB && PASSES == 3) ? kPwTab : 16;   // three-pass table kernels: the residual plane's table
     // The quantizer's table is STATIC LDS: its address is a compile-time constant, so a lookup is `ds_read_b64 v, bin`
     // with no add of the (link-time) dynamic-LDS base -- hipcc emitted one VALU add per lookup (33 in the depthwise kernel).
     __shared__ __attribute__((aligned(16))) unsigned char stab[TABB];
+    __shared__ __attribute__((aligned(16))) unsigned char stab_lo[TABL];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // everything else (sizes depend on the layer)
     uint32_t* sT = reinterpret_cast<uint32_t*>(stab);
     _Float16* wl_hi = reinterpret_cast<_Float16*>(smem);
@@ -119,6 +140,7 @@ __global__ __launch_bounds__(kStreamThreads) void k_pw_stream(const PwParams p) 
     _Float16* wl_lo = wl_hi + (size_t)wfrags * 512;
     if constexpr (TAB) enc_fill<kStreamThreads>(reinterpret_cast<uint2*>(stab), p.enc);
     else lut_fill<FMT>(sT);
+    if constexpr (TAB && PASSES == 3) enc_fill_compact<kStreamThreads>(reinterpret_cast<uint2*>(stab_lo), p.enc_lo);
     // W blob -> LDS (same fragment order), 16 bytes per thread per step
     for (int i = threadIdx.x; i < wfrags * 64; i += kStreamThreads) {
         reinterpret_cast<half8*>(wl_hi)[i] = reinterpret_cast<const half8*>(p.whi)[i];
@@ -181,7 +203,18 @@ __global__ __launch_bounds__(kStreamThreads) void k_pw_stream(const PwParams p) 
                     }
                 }
             }
-            if constexpr (TAB) {
+            if constexpr (TAB && PASSES == 3) {
+                bool any_nan = false;
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    any_nan |= enc_has_nan4(raw[c][0]) | enc_has_nan4(raw[c][1]);
+                    enc_frag_hl(raw[c][0], raw[c][1], p.enc, stab, stab_lo, xh[c0 + c], xl[c0 + c]);
+                }
+                if (__builtin_expect(any_nan, 0)) {   // NaN in -> NaN out; never taken on real activations
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) frag_patch_nan(raw[c][0], raw[c][1], xh[c0 + c]);
+                }
+            } else if constexpr (TAB) {
                 bool any_nan = false;
 #pragma unroll
                 for (int c = 0; c < CH; ++c) {
@@ -288,9 +321,9 @@ __global__ __launch_bounds__(kStreamThreads) void k_pw_stream(const PwParams p) 
 // (4 pixel rows x the wave's 64 adjacent channels) instead of 64-byte pieces, with the nt hint (SLFP_NT_PW_STG).
 template <int FMT, int PASSES, int WM, int WN, int MT, int NT, bool KFULL, bool TAB = false, bool STG = false>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 4) void k_pw_tiled(const PwParams p) {
-    static_assert(!TAB || PASSES == 1, "the table form produces the single fp16 operand");
     static_assert(!STG || NT == 4, "the staged epilogue stores a wave's 64 channels per row");
     constexpr int TABB = TAB ? kPwTab : 64;
+    constexpr int TABL = (TAB && PASSES == 3) ? kPwTab : 16;
     constexpr int T = 64 * WM * WN;
     constexpr int BM = WM * MT * 16;
     constexpr int BN = WN * NT * 16;
@@ -299,11 +332,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 4) void k_pw_til
     constexpr int XBYTES = BM * 128;
 
     __shared__ __attribute__((aligned(16))) unsigned char stab[TABB];      // static: constant address (see k_pw_stream)
+    __shared__ __attribute__((aligned(16))) unsigned char stab_lo[TABL];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* sT = reinterpret_cast<uint32_t*>(stab);
     unsigned char* xs = smem;  // [2 buffers][hi, lo][BM rows][128 B]
     if constexpr (TAB) enc_fill<T>(reinterpret_cast<uint2*>(stab), p.enc);
     else lut_fill<FMT>(sT);
+    if constexpr (TAB && PASSES == 3) enc_fill_compact<T>(reinterpret_cast<uint2*>(stab_lo), p.enc_lo);
 
     const uint32_t b = xcd_remap(blockIdx.x, p.nblocks);
     const uint32_t nb = b % p.n_blocks, mb = b / p.n_blocks;
@@ -347,7 +382,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 4) void k_pw_til
         for (int i = 0; i < NLD; ++i) {
             const int row = (threadIdx.x >> 4) + i * (T / 16);
             const uint32_t off = lds_x_off(row, st_chunk) + st_sub;
-            if constexpr (TAB) {
+            if constexpr (TAB && PASSES == 3) {
+                uint2 ph, pl;
+                enc2_f16_hl(st[i].x, st[i].y, p.enc.r1, p.enc.lo, p.enc.hi, stab, stab_lo, ph.x, pl.x);
+                enc2_f16_hl(st[i].z, st[i].w, p.enc.r1, p.enc.lo, p.enc.hi, stab, stab_lo, ph.y, pl.y);
+                if (__builtin_expect(enc_has_nan4(st[i]), 0)) enc_patch_nan4_f16(st[i], ph);
+                *reinterpret_cast<uint2*>(hi + off) = ph;
+                *reinterpret_cast<uint2*>(lo + off) = pl;
+            } else if constexpr (TAB) {
                 *reinterpret_cast<uint2*>(hi + off) = enc4_f16(st[i], p.enc.r1, p.enc.lo, p.enc.hi, stab);
             } else {
                 half4 h, l;
@@ -548,20 +590,20 @@ static int launch_tiled_k(PwParams& p, hipStream_t stream) {
     const int64_t nblocks = (int64_t)p.m_blocks * p.n_blocks;
     if (nblocks > 0x7FFFFFFF) return fail(SLFP_ERR_UNSUPPORTED, "pointwise: grid too large");
     p.nblocks = (uint32_t)nblocks;
-    if constexpr (PASSES == 1) {
-        if (p.enc.valid) {
+    {
+        if (p.enc.valid && (PASSES == 1 || p.enc_lo.valid)) {
             if constexpr (NT == 4) {
                 if (!switches().pw_nostg) {   // experiment switch (slfp_host.hpp), read once at load
-                    const size_t lds = (size_t)2 * BM * 128 + (size_t)(T / 64) * 16 * kStgRow;   // dynamic part (the table is static LDS)
-                    auto fn = k_pw_tiled<FMT, 1, WM, WN, MT, NT, KFULL, true, true>;
+                    const size_t lds = (size_t)2 * (PASSES == 3 ? 2 : 1) * BM * 128 + (size_t)(T / 64) * 16 * kStgRow;   // dynamic part (the tables are static LDS)
+                    auto fn = k_pw_tiled<FMT, PASSES, WM, WN, MT, NT, KFULL, true, true>;
                     int rc = set_lds_limit(reinterpret_cast<const void*>(fn), lds);
                     if (rc != SLFP_OK) return rc;
                     hipLaunchKernelGGL(fn, dim3(p.nblocks), dim3(T), lds, stream, p);
                     return check_launch("slfp pointwise (tiled) kernel");
                 }
             }
-            const size_t lds = (size_t)2 * BM * 128;
-            auto fn = k_pw_tiled<FMT, 1, WM, WN, MT, NT, KFULL, true>;
+            const size_t lds = (size_t)2 * (PASSES == 3 ? 2 : 1) * BM * 128;
+            auto fn = k_pw_tiled<FMT, PASSES, WM, WN, MT, NT, KFULL, true>;
             int rc = set_lds_limit(reinterpret_cast<const void*>(fn), lds);
             if (rc != SLFP_OK) return rc;
             hipLaunchKernelGGL(fn, dim3(p.nblocks), dim3(T), lds, stream, p);
@@ -584,8 +626,7 @@ static int launch_tiled(PwParams& p, hipStream_t stream) {
 
 template <int FMT, int PASSES, int KS>
 static int launch_stream_ks(PwParams& p, hipStream_t stream) {
-    bool tab = false;
-    if constexpr (PASSES == 1) tab = p.enc.valid != 0;
+    const bool tab = p.enc.valid != 0 && (PASSES == 1 || p.enc_lo.valid != 0);
     // staged 128-byte stores (with the nt hint) pay where stores dominate and follow each other closely (K <= 64: pw1
     // -14 %, pw2 -13 %) and at K = 256 (256->256 @28: 113 -> 97-105 us); at K = 128 they lose 5-8 % (same-box A/B,
     // profiles/variants.py --var SLFP_PW_STG_MAXKS=4 / 8)
@@ -594,13 +635,13 @@ static int launch_stream_ks(PwParams& p, hipStream_t stream) {
     const bool stg = tab && stg_ks && !(p.K % 4 || p.N % 4) && !switches().pw_nostg;
     const size_t lds = (size_t)(PASSES == 3 ? 2 : 1) * p.n_tiles * p.KS * 1024 + (size_t)3 * p.n_tiles * 16 * sizeof(float) +
                        (stg ? (size_t)(kStreamThreads / 64) * 2048 : 0);   // dynamic part; the table (2 KiB / 64 B) is static LDS
-    const size_t lds_total = lds + (tab ? kPwTab : 64);
+    const size_t lds_total = lds + (tab ? kPwTab * (PASSES == 3 ? 2 : 1) : 64);
     auto fn = (p.K % 4 || p.N % 4) ? k_pw_stream<FMT, PASSES, KS, false, true>
               : (p.K % 32 == 0)    ? k_pw_stream<FMT, PASSES, KS, true> : k_pw_stream<FMT, PASSES, KS, false>;
-    if constexpr (PASSES == 1) {
-        if (tab) fn = (p.K % 4 || p.N % 4) ? k_pw_stream<FMT, 1, KS, false, true, true>
-                      : (p.K % 32 == 0)    ? k_pw_stream<FMT, 1, KS, true, false, true> : k_pw_stream<FMT, 1, KS, false, false, true>;
-        if (stg) fn = (p.K % 32 == 0) ? k_pw_stream<FMT, 1, KS, true, false, true, true> : k_pw_stream<FMT, 1, KS, false, false, true, true>;
+    {
+        if (tab) fn = (p.K % 4 || p.N % 4) ? k_pw_stream<FMT, PASSES, KS, false, true, true>
+                      : (p.K % 32 == 0)    ? k_pw_stream<FMT, PASSES, KS, true, false, true> : k_pw_stream<FMT, PASSES, KS, false, false, true>;
+        if (stg) fn = (p.K % 32 == 0) ? k_pw_stream<FMT, PASSES, KS, true, false, true, true> : k_pw_stream<FMT, PASSES, KS, false, false, true, true>;
     }
     int rc = set_lds_limit(reinterpret_cast<const void*>(fn), lds);
     if (rc != SLFP_OK) return rc;
@@ -669,8 +710,13 @@ int launch_pointwise(const slfp_conv2d_desc& d, const ConvPlan& plan, const floa
     { const char* e = getenv("SLFP_PW_DBG"); p.dbg = e ? reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 16)) : nullptr; }
 #endif
     p.enc.valid = 0;
-    if (plan.passes == 1 && !switches().pw_notab) {   // experiment switch (slfp_host.hpp), read once at load
+    p.enc_lo.valid = 0;
+    if (!switches().pw_notab) {   // experiment switch (slfp_host.hpp), read once at load
         if (const EncArgs* t = act_table(d.ka, plan.fmt_act, kEncF16P)) p.enc = *t;
+        if (plan.passes == 3 && p.enc.valid) {   // three-pass mode: the residual plane's table of the same scale (round 3)
+            if (const EncArgs* t = act_table(d.ka, plan.fmt_act, kEncF16LO)) p.enc_lo = enc_compact(*t);
+            else p.enc.valid = 0;
+        }
     }
     p.s1 = plan.s1; p.s2 = plan.s2; p.s1x = plan.s1 * (1.0f / 256.0f);
     {   // staged stores always carry the nt hint: a size threshold as in conv_dw2.hip (plain stores for outputs that fit the

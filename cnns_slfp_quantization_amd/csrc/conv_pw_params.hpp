@@ -30,6 +30,7 @@ struct PwParams {
     int nt_out;           // staged (whole-line) stores carry the nt hint: outputs too large for the Infinity Cache
     PostOp post;
     EncArgs enc;          // threshold table of fp16(16 * QA(x / Ka)) (TAB kernels; slfp_enc.hpp)
+    EncArgsCompact enc_lo;   // three-pass TAB kernels: the residual plane's table (kEncF16LO) of the same scale
 #ifdef SLFP_PW_STAMPS
     unsigned long long* dbg;   // diagnostic builds only (profiles/stamps_tiled.py): 16 x s_memrealtime per workgroup
 #endif

@@ -89,6 +89,12 @@ struct Builder {
         const uint32_t v = host_quant_bits(u2f(xb), d, fmt);
         if (rep == kEncF32) return v;
         if (rep == kEncCode) return (uint32_t)host_ext_code(v, fmt);   // 0xFFFFFFFF if v is not a class value: build() then fails
+        if (rep == kEncF16LO) {   // the residual plane of the hi / lo split, as the long form computes it (conv_pw.hip: encode4)
+            const float v16 = 16.0f * u2f(v);
+            const _Float16 h = (_Float16)v16;
+            volatile float r = v16 - (float)h;
+            return f32_to_f16_bits(r);
+        }
         return f32_to_f16_bits(16.0f * u2f(v));
     }
     // smallest pattern in [a, b] with pred true (pred is false..true monotone on [a, b]; pred(b) must hold)
@@ -143,7 +149,19 @@ static bool build(float ka, int fmt, int rep, EncArgs* out) {
         }
         const uint32_t c = p & 0xFFu;
         if (rep == kEncCode && (va > 0x7Fu || vb > 0x7Fu)) return false;
+        if (rep == kEncF16LO || rep == kEncF16P) {
+            // the hi and the lo table share ONE compare per value, so both take their thresholds from the CLASS steps, also
+            // where the two classes happen to have equal halves (the computed top value 15.3216524 and the clamp literal
+            // 15.3216496 share their fp16 hi half but not their residual; selecting between equal values is harmless)
+            const uint32_t ca = host_quant_bits(u2f(xa), B.d, B.fmt), cb = host_quant_bits(u2f(xb), B.d, B.fmt);
+            X = kEncNever;
+            if (ca != cb) {
+                X = Builder::first_true(xa, xb, [&](uint32_t m) { return host_quant_bits(u2f(m), B.d, B.fmt) == cb; });
+                if (X == xa || host_quant_bits(u2f(X - 1u), B.d, B.fmt) != ca) return false;
+            }
+        }
         if (rep == kEncF32) out->e[c] = make_uint2(X, va);
+        else if (rep == kEncF16LO) out->e[c] = make_uint2(X, (va & 0xFFFFu) | (vb << 16));
         else if (rep == kEncCode) out->e[c] = make_uint2(X, va | (vb << 8));
         else out->e[c] = make_uint2(X, va | (vb << 16));
         // with the linear float32 layout the upper class of bin p is read from entry p + 1
@@ -273,6 +291,45 @@ __global__ __launch_bounds__(256) void k_code_check(const ScaleDiv sd, const Enc
     if (bad_d) atomicAdd(out + 2, bad_d);
 }
 
+// ---- exhaustive self-check of the hi / lo pair (three-pass MFMA mode): all 2^32 inputs -------------------------------
+// *out = #x whose (hi, lo) fp16 pair from enc2_f16_hl differs from the long form of conv_pw.hip's encode4:
+// v = 16 * Q(x / Ka); hi = fp16(v); lo = fp16(v - fp32(hi)).  +0 / -0 count as equal, NaN inputs are the callers' cold branch.
+template <int FMT>
+__global__ __launch_bounds__(256) void k_enc_hl_check(const ScaleDiv sd16, const EncArgs th, const EncArgsCompact tl,
+                                                      unsigned long long* __restrict__ out) {
+    __shared__ uint32_t sT[16];
+    __shared__ __attribute__((aligned(16))) uint2 sH[kEncEntries + 1], sL[kEncEntries + 1];
+    lut_fill<FMT>(sT);
+    enc_fill<256>(sH, th);
+    enc_fill_compact<256>(sL, tl);
+    __syncthreads();
+    const unsigned char* tb = reinterpret_cast<const unsigned char*>(sH);
+    const unsigned char* tlo = reinterpret_cast<const unsigned char*>(sL);
+    unsigned long long bad = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * 256 * 2;
+    for (uint64_t i = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 2; i < (1ull << 32); i += stride) {
+        const float xa = __uint_as_float((uint32_t)i), xb = __uint_as_float((uint32_t)i + 1u);
+        uint32_t hp, lp;
+        enc2_f16_hl(xa, xb, th.r1, th.lo, th.hi, tb, tlo, hp, lp);
+        const float xs[2] = {xa, xb};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if (xs[e] != xs[e]) continue;
+            const float v = quantize_scaled<FMT, 4>(xs[e], sd16, sT);
+            const _Float16 h = (_Float16)v;
+            const _Float16 l = (_Float16)(v - (float)h);
+            uint16_t hb, lb;
+            __builtin_memcpy(&hb, &h, 2);
+            __builtin_memcpy(&lb, &l, 2);
+            const uint32_t gh = (hp >> (16 * e)) & 0xFFFFu, gl = (lp >> (16 * e)) & 0xFFFFu;
+            const bool h_ok = gh == hb || ((gh | hb) & 0x7FFFu) == 0u;
+            const bool l_ok = gl == lb || ((gl | lb) & 0x7FFFu) == 0u;
+            if (!h_ok || !l_ok) ++bad;
+        }
+    }
+    if (bad) atomicAdd(out, bad);
+}
+
 }  // namespace slfp
 
 using namespace slfp;
@@ -318,4 +375,22 @@ extern "C" int slfp_debug_code_mismatches(float scale_div, int fmt, unsigned lon
     if (fmt == SLFP_FMT_ACT8) hipLaunchKernelGGL((k_code_check<kFmtAct8>), dim3(256 * 16), dim3(256), 0, st, sd, *t, out3);
     else hipLaunchKernelGGL((k_code_check<kFmtSfp7>), dim3(256 * 16), dim3(256), 0, st, sd, *t, out3);
     return check_launch("slfp code-table self-check kernel");
+}
+
+// The three-pass (float32-equivalent) pointwise mode's table encoder (csrc/slfp_enc.hpp: enc2_f16_hl): ALL 2^32 float32
+// inputs against the long form.  *out1 must be 0.
+extern "C" int slfp_debug_enc_hl_mismatches(float scale_div, int fmt, unsigned long long* out1, void* stream) {
+    if (!out1 || !(scale_div > 0.f)) return fail(SLFP_ERR_BAD_ARG, "slfp_debug_enc_hl_mismatches: bad argument");
+    if (fmt != SLFP_FMT_ACT8 && fmt != SLFP_FMT_SFP7) return fail(SLFP_ERR_BAD_ARG, "slfp_debug_enc_hl_mismatches: fmt must be ACT8 or SFP7");
+    if (!scale_div_ok(scale_div)) return fail(SLFP_ERR_UNSUPPORTED, "scale must be within [1e-30, 1e30]");
+    const EncArgs* th = enc_table(scale_div, fmt, kEncF16P);
+    const EncArgs* tl = enc_table(scale_div, fmt, kEncF16LO);
+    if (!th->valid || !tl->valid) return fail(SLFP_ERR_UNSUPPORTED, "no hi / lo threshold tables for scale %g", (double)scale_div);
+    hipStream_t st = as_stream(stream);
+    if (hipMemsetAsync(out1, 0, sizeof(unsigned long long), st) != hipSuccess) return check_launch("hipMemsetAsync");
+    const ScaleDiv sd16 = make_scale_div(scale_div, 4);
+    const EncArgsCompact tc = enc_compact(*tl);
+    if (fmt == SLFP_FMT_ACT8) hipLaunchKernelGGL((k_enc_hl_check<kFmtAct8>), dim3(256 * 16), dim3(256), 0, st, sd16, *th, tc, out1);
+    else hipLaunchKernelGGL((k_enc_hl_check<kFmtSfp7>), dim3(256 * 16), dim3(256), 0, st, sd16, *th, tc, out1);
+    return check_launch("slfp hi/lo table self-check kernel");
 }

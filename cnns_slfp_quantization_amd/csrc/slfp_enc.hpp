@@ -38,6 +38,8 @@ constexpr uint32_t kEncNever = 0x7FC00000u;  // X of a bin without a step: |x| >
 // value representations
 constexpr int kEncF32 = 0;   // V = float32 bits of Q(x/Ka); Vnext = the next entry's V
 constexpr int kEncF16P = 1;  // V = fp16(16 * Q) of the lower class | fp16(16 * Q) of the upper class << 16
+constexpr int kEncF16LO = 3; // V = the fp16 RESIDUALS of the same two classes: fp16(16 Q - fp32(fp16(16 Q))): with kEncF16P the hi / lo
+                             // operand pair of the three-pass (float32-equivalent) MFMA mode (round 3)
 
 struct EncArgs {
     float r1, lo, hi;
@@ -148,6 +150,38 @@ __device__ __forceinline__ uint32_t enc2_f16(float xa, float xb, const float r1,
         : "v"(xa), "v"(ea.x), "v"(ea.y), "v"(xb), "v"(eb.x), "v"(eb.y), "s"(0x07060302u), "s"(0x7FFF7FFFu)
         : "vcc");
     return out;
+}
+
+// The hi / lo fp16 operand pair of two consecutive values for the three-pass MFMA mode: `sTab` is the kEncF16P table, `sLo`
+// the kEncF16LO table of the same scale (same bins, same thresholds: ONE estimate and ONE compare per value select both
+// halves).  hi carries x's sign (v_bfi), lo -- which has a sign of its own -- is flipped where x is negative (v_xor).
+__device__ __forceinline__ void enc2_f16_hl(float xa, float xb, const float r1, const float lo, const float hi,
+                                            const unsigned char* __restrict__ sTab, const unsigned char* __restrict__ sLo,
+                                            uint32_t& out_hi, uint32_t& out_lo) {
+    const float qa = __builtin_amdgcn_fmed3f(__builtin_fabsf(xa) * r1, lo, hi);
+    const float qb = __builtin_amdgcn_fmed3f(__builtin_fabsf(xb) * r1, lo, hi);
+    const uint32_t oa = enc_bin_off(qa), ob = enc_bin_off(qb);
+    const uint2 ea = *reinterpret_cast<const uint2*>(sTab + oa);
+    const uint2 eb = *reinterpret_cast<const uint2*>(sTab + ob);
+    const uint32_t la = *reinterpret_cast<const uint32_t*>(sLo + oa + 4);
+    const uint32_t lb = *reinterpret_cast<const uint32_t*>(sLo + ob + 4);
+    uint32_t d, l, sg, oh, ol;
+    asm("v_cmp_ge_f32_e64 vcc, |%5|, %6\n\t"
+        "v_cndmask_b32_sdwa %0, %7, %7, vcc dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t"
+        "v_cndmask_b32_sdwa %1, %8, %8, vcc dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t"
+        "v_cmp_ge_f32_e64 vcc, |%9|, %10\n\t"
+        "v_cndmask_b32_sdwa %0, %11, %11, vcc dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_1\n\t"
+        "v_cndmask_b32_sdwa %1, %12, %12, vcc dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_1\n\t"
+        "v_perm_b32 %2, %9, %5, %13\n\t"
+        "v_bfi_b32 %3, %14, %0, %2\n\t"
+        "v_and_b32 %2, %15, %2\n\t"
+        "v_xor_b32 %4, %1, %2"
+        : "=&v"(d), "=&v"(l), "=&v"(sg), "=&v"(oh), "=&v"(ol)
+        : "v"(xa), "v"(ea.x), "v"(ea.y), "v"(la), "v"(xb), "v"(eb.x), "v"(eb.y), "v"(lb), "s"(0x07060302u), "s"(0x7FFF7FFFu),
+          "s"(0x80008000u)
+        : "vcc");
+    out_hi = oh;
+    out_lo = ol;
 }
 
 // four consecutive values -> two packed registers; NaN inputs NOT patched (see enc_has_nan4 / enc_patch_nan4_f16)

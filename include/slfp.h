@@ -226,6 +226,9 @@ int slfp_debug_div_mismatches(float scale_div, unsigned long long* out2, void* s
  * result differs (+0 / -0 counted as equal).  Both must be 0.  fmt: SLFP_FMT_ACT8 or SLFP_FMT_SFP7.
  * Returns SLFP_ERR_UNSUPPORTED if no table can be proven for this scale (the kernels then use the long form). */
 int slfp_debug_enc_mismatches(float scale_div, int fmt, unsigned long long* out2, void* stream);
+/* The same for the hi / lo fp16 operand pair of the three-pass (float32-equivalent) pointwise mode (round 3): *out1 = inputs
+ * (all 2^32) whose pair from the two tables differs from hi = fp16(16 Q), lo = fp16(16 Q - fp32(hi)).  Must be 0. */
+int slfp_debug_enc_hl_mismatches(float scale_div, int fmt, unsigned long long* out1, void* stream);
 /* 1 if the threshold table exists for this scale / format (host-only query, no device work). */
 int slfp_enc_table_ok(float scale_div, int fmt);
 
