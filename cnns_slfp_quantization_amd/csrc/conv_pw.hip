@@ -319,8 +319,13 @@ __global__ __launch_bounds__(kStreamThreads) void k_pw_stream(const PwParams p) 
 // in the middle of the MFMA block, draining the HBM loads it has just issued (r01c ISA).
 // STG: the epilogue goes through a per-wave LDS staging area so that every store instruction writes whole 256-byte runs
 // (4 pixel rows x the wave's 64 adjacent channels) instead of 64-byte pieces, with the nt hint (SLFP_NT_PW_STG).
-template <int FMT, int PASSES, int WM, int WN, int MT, int NT, bool KFULL, bool TAB = false, bool STG = false>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 4) void k_pw_tiled(const PwParams p) {
+// PF (MT = 8 tiling: 128 pixels x 512 channels, ONE workgroup per CU, 256 registers per lane): the registers that the second
+// workgroup gave up hold the W fragments of a whole stage one stage ahead, so the only vmcnt wait of a stage is for loads
+// issued a full stage earlier -- X (HBM) and W (L2) retire in order through one counter, and with a one-k-step W lead every
+// W wait also waited for the X loads issued just before it (profiles/notes: the ablation of round 3).
+template <int FMT, int PASSES, int WM, int WN, int MT, int NT, bool KFULL, bool TAB = false, bool STG = false, bool PF = false>
+__global__ __launch_bounds__(64 * WM * WN, (MT > 4 || (WM * WN) <= 4) ? 2 : 4) void k_pw_tiled(const PwParams p) {
+    static_assert(!PF || (KFULL && TAB && STG && PASSES == 1), "the prefetching loop is built for the table encoder, staged stores, K % 128 == 0");
     static_assert(!STG || NT == 4, "the staged epilogue stores a wave's 64 channels per row");
     constexpr int TABB = TAB ? kPwTab : 64;
     constexpr int TABL = (TAB && PASSES == 3) ? kPwTab : 16;
@@ -343,7 +348,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 4) void k_pw_til
     const uint32_t b = xcd_remap(blockIdx.x, p.nblocks);
     const uint32_t nb = b % p.n_blocks, mb = b / p.n_blocks;
     const int64_t m0 = (int64_t)mb * p.rb;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = PF ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : (int)(threadIdx.x >> 6);   // PF: scalar W bases
     const int wm = wave / WN, wn = wave % WN;
     const int col = lane & 15, kq = lane >> 4;
 
@@ -363,6 +369,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 4) void k_pw_til
 
     float4 st[NLD];
     auto load_stage = [&](int t) {
+#ifdef SLFP_ABL_NOX   // diagnostic builds only (profiles/ablate_pw.sh): wrong results, what does the kernel cost without ...
+        if (t >= 2) {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) asm volatile("" : "+v"(st[i].x), "+v"(st[i].y), "+v"(st[i].z), "+v"(st[i].w));
+            return;
+        }
+#endif
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             if constexpr (KFULL) {
@@ -390,7 +403,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 4) void k_pw_til
                 *reinterpret_cast<uint2*>(hi + off) = ph;
                 *reinterpret_cast<uint2*>(lo + off) = pl;
             } else if constexpr (TAB) {
+#ifdef SLFP_ABL_NOENC
+                uint2 pk;
+                pk.x = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(st[i].x, st[i].y));
+                pk.y = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(st[i].z, st[i].w));
+                *reinterpret_cast<uint2*>(hi + off) = pk;
+#else
                 *reinterpret_cast<uint2*>(hi + off) = enc4_f16(st[i], p.enc.r1, p.enc.lo, p.enc.hi, stab);
+#endif
             } else {
                 half4 h, l;
                 encode4<FMT, PASSES>(st[i], p.sd, sT, h, l);
@@ -417,6 +437,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 4) void k_pw_til
     }
     half8 wh[NT], wl[NT];
     auto load_w = [&](int kstep) {
+#ifdef SLFP_ABL_NOW
+        if (kstep >= 1) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) asm volatile("" : "+v"(wh[j]));
+            return;
+        }
+#endif
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             wh[j] = *reinterpret_cast<const half8*>(wbase[j] + (size_t)kstep * 512);
@@ -439,11 +466,74 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 4) void k_pw_til
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[j], xh, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], xl, acc[i][j], 0, 0, 0);
                 }
+#ifdef SLFP_ABL_NOMFMA
+                asm volatile("" :: "v"(wh[j]), "v"(xh));
+#else
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], xh, acc[i][j], 0, 0, 0);
+#endif
             }
         }
     };
 
+    if constexpr (PF) {
+        half8 wA[2][NT], wB[2][NT];
+        const _Float16* wuni[NT];   // wave-uniform fragment bases (scalar registers) + one lane offset
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int nt = ntile0 + j < p.n_tiles ? ntile0 + j : p.n_tiles - 1;
+            wuni[j] = p.whi + (size_t)nt * p.KS * 512;
+        }
+        const uint32_t lane8 = (uint32_t)lane * 8u;
+        auto load_w2 = [&](half8 (&w)[2][NT], int stage) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    w[ks][j] = *reinterpret_cast<const half8*>(wuni[j] + (size_t)(stage * 2 + ks) * 512 + lane8);
+        };
+        auto mfma2 = [&](int buf, const half8 (&w)[2][NT]) {
+            const unsigned char* hi = xs + (size_t)buf * XBYTES;
+            auto xfrag = [&](int s) {   // step s = (k-step, pixel tile)
+                const int row = (wm * MT + (s % MT)) * 16 + col;
+                return *reinterpret_cast<const half8*>(hi + lds_x_off(row, (s / MT) * 4 + kq));
+            };
+            half8 xh[2];
+            xh[0] = xfrag(0);
+#pragma unroll
+            for (int s2 = 0; s2 < 2 * MT; ++s2) {
+                if (s2 + 1 < 2 * MT) xh[(s2 + 1) & 1] = xfrag(s2 + 1);   // the next X fragment is in flight under these MFMAs
+#pragma unroll
+                for (int j = 0; j < NT; ++j)   // accumulators pinned to the acc half of the register file: 128 acc + <= 128 arch
+                    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[s2 % MT][j]) : "v"(w[s2 / MT][j]), "v"(xh[s2 & 1]));
+            }
+        };
+        auto body = [&](int t, int buf, const half8 (&cur)[2][NT], half8 (&nxt)[2][NT]) {
+            load_w2(nxt, t + 1 < KT ? t + 1 : KT - 1);     // next stage's W: consumed one whole stage from now
+            __builtin_amdgcn_sched_barrier(0);
+            encode_store(buf ^ 1);                         // X of stage t+1 (requested one stage ago) -> the other LDS buffer
+            load_stage(t + 2 < KT ? t + 2 : KT - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma2(buf, cur);
+            __syncthreads();
+        };
+        SLFP_STAMP(0);
+        __syncthreads();  // table visible
+        SLFP_STAMP(1);
+        load_stage(0);
+        encode_store(0);
+        load_w2(wA, 0);
+        load_stage(KT > 1 ? 1 : 0);
+        __syncthreads();
+        SLFP_STAMP(2);
+        for (int t = 0; t < KT; t += 2) {   // KT is even (launcher)
+            body(t, 0, wA, wB);
+            SLFP_STAMP(3 + (t < 8 ? t : 8));
+            body(t + 1, 1, wB, wA);
+            SLFP_STAMP(3 + (t + 1 < 8 ? t + 1 : 8));
+        }
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the MFMAs are opaque asm: let the last ones retire before acc is read
+        SLFP_STAMP(12);
+    } else {
     SLFP_STAMP(0);
     __syncthreads();  // LUT visible
     SLFP_STAMP(1);
@@ -487,6 +577,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 4) void k_pw_til
         mfma_step(buf, 0);
         load_w(t * 2 + 1);
         mfma_step(buf, 1);
+    }
     }
 
     // fused BN/ReLU: this workgroup's BN-channel slices of scale / shift go through the (now free) X tile
@@ -537,6 +628,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 4) void k_pw_til
                 const u32x4 v = *reinterpret_cast<const u32x4*>(stg + (h * 4 + srow) * kStgRow + sch * 16);
                 const bool ok = row < p.rb && m0 + row < p.M && n_st < p.N;
                 uint32_t so = ok ? (uint32_t)(row * p.N + n_st) * 4u : 0xFFFFFFF0u;
+#ifdef SLFP_ABL_NOST
+                so = 0xFFFFFFF0u;
+#endif
                 asm volatile("" : "+v"(so));
                 if (p.nt_out) __builtin_amdgcn_raw_buffer_store_b128(v, ry, so, 0, 2);
                     else __builtin_amdgcn_raw_buffer_store_b128(v, ry, so, 0, 0);
@@ -578,7 +672,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 4) void k_pw_til
 // once per (device, kernel), not per launch (round 1 re-armed the attribute on every launch)
 static int set_lds_limit(const void* fn, size_t lds) { return raise_lds_limit(fn, lds); }
 
-template <int FMT, int PASSES, int WM, int WN, int MT, int NT, bool KFULL>
+template <int FMT, int PASSES, int WM, int WN, int MT, int NT, bool KFULL, bool PF = false>
 static int launch_tiled_k(PwParams& p, hipStream_t stream) {
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16, T = 64 * WM * WN;
     p.n_blocks = (uint32_t)ceil_div((int64_t)p.N, BN);
@@ -595,7 +689,7 @@ static int launch_tiled_k(PwParams& p, hipStream_t stream) {
             if constexpr (NT == 4) {
                 if (!switches().pw_nostg) {   // experiment switch (slfp_host.hpp), read once at load
                     const size_t lds = (size_t)2 * (PASSES == 3 ? 2 : 1) * BM * 128 + (size_t)(T / 64) * 16 * kStgRow;   // dynamic part (the tables are static LDS)
-                    auto fn = k_pw_tiled<FMT, PASSES, WM, WN, MT, NT, KFULL, true, true>;
+                    auto fn = k_pw_tiled<FMT, PASSES, WM, WN, MT, NT, KFULL, true, true, PF>;
                     int rc = set_lds_limit(reinterpret_cast<const void*>(fn), lds);
                     if (rc != SLFP_OK) return rc;
                     hipLaunchKernelGGL(fn, dim3(p.nblocks), dim3(T), lds, stream, p);
@@ -686,6 +780,9 @@ static int launch_pw(PwParams& p, const ConvPlan& plan, hipStream_t stream) {
         // widest channel tile: fewest re-reads / re-encodes of X.  (Narrower tiles for the small-M, deep-K
         // layers of ResNet-50's last stages -- 49-196 pixel tiles at batch 64 -- were measured: more
         // workgroups, but the redundant encode costs more than the idle CUs did.)
+        if (p.N > 256 && switches().pw_mt8 == 1) return launch_tiled<FMT, 1, 1, 8, 8, 4>(p, stream);  // 128 px x 512 ch, 8 waves, 1 workgroup/CU
+        if (p.N > 256 && switches().pw_mt8 == 2 && p.K % 128 == 0 && p.enc.valid && !switches().pw_nostg)
+            return launch_tiled_k<FMT, 1, 1, 8, 8, 4, true, true>(p, stream);                         // + W a whole stage ahead
         if (p.N > 256) return launch_tiled<FMT, 1, 1, 8, 4, 4>(p, stream);  // 64 px x 512 ch, 8 waves, 2 workgroups/CU
         if (p.N > 128) return launch_tiled<FMT, 1, 1, 4, 4, 4>(p, stream);  // 64 px x 256 ch
         if (p.N > 64) return launch_tiled<FMT, 1, 2, 2, 2, 4>(p, stream);   // 64 px x 128 ch
