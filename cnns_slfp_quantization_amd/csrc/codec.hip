@@ -78,8 +78,6 @@ static Switches read_switches() {
     w.dense_nwb = e ? atoi(e) : 0;
     e = std::getenv("SLFP_PW_STREAM_MAX_KB");
     w.pw_stream_max_kb = e ? atoi(e) : 128;
-    e = std::getenv("SLFP_PW_MT8");
-    w.pw_mt8 = e ? atoi(e) : 0;
     return w;
 }
 static Switches g_switches = read_switches();   // once, at load

@@ -58,7 +58,6 @@ struct Switches {
     int dense_cfg;            // SLFP_DENSE_CFG=<wm><wn><mt> (e.g. 244): force a dense k x k tiling where it fits (sweeps); 0 = cost model
     int dense_nwb;            // SLFP_DENSE_NWB=2: keep two weight buffers everywhere (A/B of the three-buffer pipeline)
     int pw_stream_max_kb;     // SLFP_PW_STREAM_MAX_KB: largest W (KiB, fp16) the LDS-resident stream kernel takes (default 128)
-    int pw_mt8;               // SLFP_PW_MT8=1: C_out > 256 pointwise on the 128-pixel tiling (one workgroup per CU, 256 registers)
 };
 const Switches& switches();
 void reload_switches();
