@@ -68,7 +68,7 @@ static Switches read_switches() {
     e = std::getenv("SLFP_PW_NT_MIN_MB");
     w.pw_nt_min_mb = e ? atoll(e) : 0;
     e = std::getenv("SLFP_DW_NT_MIN_MB");
-    w.dw_nt_min_mb = e ? atoll(e) : 120;
+    w.dw_nt_min_mb = e ? atoll(e) : 30;   // round 3, 200-step same-box A/B (profiles/ab_env_long.sh): 30 / 0 / 120 / 210 MB -> 118.41 / 118.34 / 118.03 / 117.65 k images/s
     w.stem_old = std::getenv("SLFP_STEM_OLD") != nullptr;
     w.pwc_slice = std::getenv("SLFP_PWC_NOSLICE") == nullptr;
     w.dense_generic = std::getenv("SLFP_DENSE_GENERIC") != nullptr;
@@ -77,7 +77,7 @@ static Switches read_switches() {
     e = std::getenv("SLFP_DENSE_NWB");
     w.dense_nwb = e ? atoi(e) : 0;
     e = std::getenv("SLFP_PW_STREAM_MAX_KB");
-    w.pw_stream_max_kb = e ? atoi(e) : 128;
+    w.pw_stream_max_kb = e ? atoi(e) : 100;   // 256 -> 256 (128 KiB of W) runs on the tiled kernel: 107.7 vs 112.5 us, step -0.5 % (ab_env_long.sh)
     return w;
 }
 static Switches g_switches = read_switches();   // once, at load

@@ -656,10 +656,12 @@ template <int FMT, int PASSES, int KS>
 static int launch_stream_ks(PwParams& p, hipStream_t stream) {
     const bool tab = p.enc.valid != 0 && (PASSES == 1 || p.enc_lo.valid != 0);
     // staged 128-byte stores (with the nt hint) pay where stores dominate and follow each other closely (K <= 64: pw1
-    // -14 %, pw2 -13 %) and at K = 256 (256->256 @28: 113 -> 97-105 us); at K = 128 they lose 5-8 % (same-box A/B,
-    // profiles/variants.py --var SLFP_PW_STG_MAXKS=4 / 8)
+    // -14 %, pw2 -13 %) and at K = 256 (256->256 @28: 113 -> 97-105 us).  At K = 128 the layer itself loses 5-8 % (profiles/
+    // variants.py --var SLFP_PW_STG_MAXKS=4 / 8) but the depthwise layer that reads its output gains more (whole step, 200-step
+    // same-box A/B profiles/ab_env_long.sh, 3 rounds: depthwise family 1.035 -> 0.997 ms, pointwise 1.098 -> 1.112, step -1 %):
+    // staged everywhere since round 3.  K = 160 / 192 (KS 5..6: no MobileNetV1 layer) keep the direct stores they were measured with
     const int mk = switches().pw_stg_maxks;   // experiment switch (slfp_host.hpp), read once at load
-    const bool stg_ks = mk >= 0 ? KS <= mk : (KS <= 2 || KS == 8);
+    const bool stg_ks = mk >= 0 ? KS <= mk : (KS <= 4 || KS == 8);
     const bool stg = tab && stg_ks && !(p.K % 4 || p.N % 4) && !switches().pw_nostg;
     const size_t lds = (size_t)(PASSES == 3 ? 2 : 1) * p.n_tiles * p.KS * 1024 + (size_t)3 * p.n_tiles * 16 * sizeof(float) +
                        (stg ? (size_t)(kStreamThreads / 64) * 2048 : 0);   // dynamic part; the table (2 KiB / 64 B) is static LDS

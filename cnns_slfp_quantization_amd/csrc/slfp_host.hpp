@@ -51,13 +51,13 @@ struct Switches {
     bool long_encode, dw_old, pw_nostg, pw_notab;
     int pw_stg_maxks;         // -1: default rule
     long long pw_nt_min_mb;   // default 0
-    long long dw_nt_min_mb;   // default 120
+    long long dw_nt_min_mb;   // default 30
     bool stem_old;            // SLFP_STEM_OLD: the MobileNetV1 stem on the vector ALU (k_stem_fixed) instead of the float32 MFMA kernel (k_stem_mx)
     bool pwc_slice;           // SLFP_PWC_NOSLICE unsets it: deep code-path pointwise layers on k_pwc_tiled / k_pwc_stream instead of k_pwc_slice
     bool dense_generic;       // SLFP_DENSE_GENERIC: 3x3 stride-1 layers on the general k_dense_mfma instead of the unrolled k_dense3x3
     int dense_cfg;            // SLFP_DENSE_CFG=<wm><wn><mt> (e.g. 244): force a dense k x k tiling where it fits (sweeps); 0 = cost model
     int dense_nwb;            // SLFP_DENSE_NWB=2: keep two weight buffers everywhere (A/B of the three-buffer pipeline)
-    int pw_stream_max_kb;     // SLFP_PW_STREAM_MAX_KB: largest W (KiB, fp16) the LDS-resident stream kernel takes (default 128)
+    int pw_stream_max_kb;     // SLFP_PW_STREAM_MAX_KB: largest W (KiB, fp16) the LDS-resident stream kernel takes (default 100)
 };
 const Switches& switches();
 void reload_switches();
