@@ -272,7 +272,8 @@ def _hip_conv2d_codes(mod, x, weight, bias):
         post = mod._post
         flags = int(post[2]) if post is not None else 0
         ok = bool(L.slfp_conv2d_codes_supported(ctypes.byref(d), ctypes.byref(io), 1 if bias is not None else 0, flags))
-        plan = _Plan(d, ho.value, wo.value, 0, L.slfp_conv2d_kernel_name(ctypes.byref(d)).decode())
+        plan = _Plan(d, ho.value, wo.value, L.slfp_conv2d_workspace_bytes(ctypes.byref(d)) if ok else 0,
+                     L.slfp_conv2d_kernel_name(ctypes.byref(d)).decode())
         plan.io, plan.codes_ok = io, ok
         if len(mod._plans) >= 64:
             mod._plans.clear()
@@ -297,10 +298,12 @@ def _hip_conv2d_codes(mod, x, weight, bias):
             if ps is not None and ps.device != x.device:
                 ps, psh = ps.to(x.device), psh.to(x.device)
                 mod._post = (ps, psh, relu)
-        _lib.check(L.slfp_conv2d_fwd_codes(ctypes.byref(d), ctypes.byref(plan.io), x.data_ptr(), blob.data_ptr(),
-                                           b.data_ptr() if b is not None else None,
-                                           ps.data_ptr() if ps is not None else None,
-                                           psh.data_ptr() if psh is not None else None, int(relu), y.data_ptr(), _stream_handle(x)))
+        ws = _workspace(x.device, plan.ws_bytes) if plan.ws_bytes else None   # dense k x k layers: the fp16 operand copy
+        _lib.check(L.slfp_conv2d_fwd_codes_ws(ctypes.byref(d), ctypes.byref(plan.io), x.data_ptr(), blob.data_ptr(),
+                                              b.data_ptr() if b is not None else None,
+                                              ps.data_ptr() if ps is not None else None,
+                                              psh.data_ptr() if psh is not None else None, int(relu), y.data_ptr(),
+                                              ws.data_ptr() if ws is not None else None, _stream_handle(x)))
     mod._last_kernel = plan.kernel + ("+codes_in" if x_codes else "") + ("+codes_out" if out is not None else "")
     if x_codes:
         mod._last_input, mod._last_codes = None, x.detach()

@@ -409,7 +409,7 @@ int slfp_conv2d_fwd_post(const slfp_conv2d_desc* d, const float* x, const void* 
 
 // ---- 1-byte activation codes between layers (include/slfp.h; csrc/slfp_codes.hpp) ----
 static int codes_route(const slfp_conv2d_desc* d, const slfp_conv2d_io* io, bool has_bias, int relu, ConvPlan* p) {
-    // 0: unsupported; 1: depthwise on codes; 2: pointwise on codes; 3: image stem with code output
+    // 0: unsupported; 1: depthwise on codes; 2: pointwise on codes; 3: image stem with code output; 4: dense k x k (needs workspace)
     if (!d || !io) return 0;
     if (make_plan(d, p) != SLFP_OK) return 0;
     if (d->x_layout != SLFP_LAYOUT_NHWC || d->y_layout != SLFP_LAYOUT_NHWC) return 0;
@@ -423,9 +423,11 @@ static int codes_route(const slfp_conv2d_desc* d, const slfp_conv2d_io* io, bool
     if (io->x_codes) {
         if (dwc_applicable(*d, *p, has_bias ? reinterpret_cast<const float*>(1) : nullptr, relu)) return 1;
         if (pwc_applicable(*d, *p, relu, io->y_codes != 0)) return 2;
+        if (dense_codes_applicable(*d, *p, relu, io->y_codes != 0)) return 4;
         return 0;
     }
     if (io->y_codes && stem_codes_applicable(*d, *p, relu)) return 3;
+    if (io->y_codes && dense_codes_applicable(*d, *p, relu, true)) return 4;
     return 0;
 }
 
@@ -437,6 +439,12 @@ extern "C" int slfp_conv2d_codes_supported(const slfp_conv2d_desc* d, const slfp
 extern "C" int slfp_conv2d_fwd_codes(const slfp_conv2d_desc* d, const slfp_conv2d_io* io, const void* x, const void* wprep,
                                      const float* bias, const float* post_scale, const float* post_shift, int relu, void* y,
                                      void* stream) {
+    return slfp_conv2d_fwd_codes_ws(d, io, x, wprep, bias, post_scale, post_shift, relu, y, nullptr, stream);
+}
+
+extern "C" int slfp_conv2d_fwd_codes_ws(const slfp_conv2d_desc* d, const slfp_conv2d_io* io, const void* x, const void* wprep,
+                                        const float* bias, const float* post_scale, const float* post_shift, int relu, void* y,
+                                        void* workspace, void* stream) {
     if (!d || !io) return fail(SLFP_ERR_BAD_ARG, "slfp_conv2d_fwd_codes: null descriptor");
     ConvPlan p;
     int rc = make_plan(d, &p);
@@ -459,6 +467,13 @@ extern "C" int slfp_conv2d_fwd_codes(const slfp_conv2d_desc* d, const slfp_conv2
                           io->y_codes != 0, io->y_ka, y_fmt, st);
     if (route == 2)
         return launch_pwc(*d, p, reinterpret_cast<const uint8_t*>(x), wprep, bias, post, y, io->y_codes != 0, io->y_ka, y_fmt, st);
+    if (route == 4) {
+        const size_t ws_need = workspace_bytes_for(d, p);
+        if (ws_need && (!workspace || !aligned16(workspace)))
+            return fail(SLFP_ERR_BAD_ARG, "slfp_conv2d_fwd_codes_ws: %zu bytes of 16-byte aligned workspace required (slfp_conv2d_workspace_bytes)", ws_need);
+        const CodeIo cio{io->x_codes != 0, io->y_codes != 0, io->y_ka, y_fmt};
+        return launch_dense_mfma_io(*d, p, x, wprep, bias, post, y, workspace, cio, st);
+    }
     const CodeIo cio{false, true, io->y_ka, y_fmt};
     return launch_stem_codes(*d, p, reinterpret_cast<const float*>(x), reinterpret_cast<const float*>(wprep), bias, post, y, cio, st);
 }

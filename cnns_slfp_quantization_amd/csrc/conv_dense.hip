@@ -26,6 +26,7 @@
 // float32-equivalent (SLFP_MFMA_F16X3: hi + lo fp16 planes of both operands, 3 MFMAs per tile; stride-2
 // layers, whose halo tiles do not fit twice in LDS, stay on k_direct in that mode).
 #include "slfp_device.hpp"
+#include "slfp_codes.hpp"
 #include "slfp_host.hpp"
 
 namespace slfp {
@@ -56,6 +57,11 @@ struct DenseParams {
     float s1, s2, s1x;
     PostOp post;
     uint32_t nblocks;
+    // 1-byte codes out (slfp_codes.hpp): the epilogue applies the CONSUMER's quantizer QA(. / y_ka) and stores extended codes
+    uint8_t* yc;          // != nullptr: code output (y is unused)
+    int y_sgn;            // no ReLU in front of the output quantizer: codes carry a sign
+    int y_fmt;            // kFmtAct8 | kFmtSfp7
+    EncArgs enc_out;      // kEncCode table of (y_ka, y_fmt); filled into LDS after the main loop
 };
 
 __device__ __forceinline__ uint32_t dn_x_off(int row, int chunk16) {
@@ -110,6 +116,121 @@ __global__ __launch_bounds__(256) void k_dense_encode(const float* __restrict__ 
     }
     if (lo) *reinterpret_cast<half8*>(lo + idx * 8) = l;
     *reinterpret_cast<half8*>(xe + idx * 8) = h;
+}
+
+// The same copy from 1-byte codes (slfp_codes.hpp): the producer already applied this layer's QA(. / Ka), so a byte decodes to
+// exactly the value k_dense_encode would have computed from the float32 tensor -- the GEMM that follows is bit-identical.
+template <int FMT>
+__global__ __launch_bounds__(256) void k_dense_decode(const uint8_t* __restrict__ x, _Float16* __restrict__ xe,
+                                                      _Float16* __restrict__ lo, unsigned char* __restrict__ zero_page,
+                                                      int64_t n_chunks16, int C, int Cp) {
+    __shared__ __attribute__((aligned(16))) uint32_t sDec[256];
+    dec_fill<FMT, kDecF32, 256>(sDec);
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x < 16) reinterpret_cast<uint4*>(zero_page)[threadIdx.x] = make_uint4(0, 0, 0, 0);
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_chunks16) return;
+    const int per_pix = Cp >> 3;
+    const int64_t pix = idx / per_pix;
+    const int cj = (int)(idx - pix * per_pix);
+    const int c0 = (cj >> 2) * 32 + (cj & 3) * 4;
+    const uint8_t* xp = x + pix * C;
+    const unsigned char* dt = reinterpret_cast<const unsigned char*>(sDec);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    if (c0 < C) a = dec4_f32(*reinterpret_cast<const uint32_t*>(xp + c0), dt);
+    if (c0 + 16 < C) b = dec4_f32(*reinterpret_cast<const uint32_t*>(xp + c0 + 16), dt);
+    const float v[8] = {16.f * a.x, 16.f * a.y, 16.f * a.z, 16.f * a.w, 16.f * b.x, 16.f * b.y, 16.f * b.z, 16.f * b.w};
+    half8 h, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const bool pad = c0 + (j >> 2) * 16 >= C;
+        h[j] = pad ? (_Float16)0.f : (_Float16)v[j];
+        l[j] = pad ? (_Float16)0.f : (_Float16)(v[j] - (float)h[j]);
+    }
+    if (lo) *reinterpret_cast<half8*>(lo + idx * 8) = l;
+    *reinterpret_cast<half8*>(xe + idx * 8) = h;
+}
+
+// Epilogue of both GEMM kernels: Conv2d_Q's (acc * Ka) * Kw with the reference's two roundings, the fused post-op, and either
+// float32 stores (16 bytes per lane: 4 consecutive channels of one pixel) or the consumer's 1-byte codes.  Code output: the 4
+// channel tiles of a wave are encoded, transposed across the lane quarters (rows_transpose4) so that a lane holds 16
+// CONSECUTIVE channels of its pixel, and stored as one 16-byte piece.
+template <int MT>
+__device__ __forceinline__ void dense_epilogue(const DenseParams& p, const floatx4 (&acc)[MT][4], unsigned char* smem, int n, int th,
+                                               int tw, int TH, int wm, int wn, int nt0, int col, int kq) {
+    const int gow = tw * kDnTW + col;
+    if (p.yc) {
+        __syncthreads();   // every wave has left the main loop: the operand tiles in LDS are dead
+        enc_fill<kDnThreads>(reinterpret_cast<uint2*>(smem), p.enc_out);
+        __syncthreads();
+        const float r1 = p.enc_out.r1, lo = p.enc_out.lo, hi = p.enc_out.hi;
+        const int chw = (nt0 + wn * 4) * 16;   // this wave's 64 channels
+        float4 bq[4];
+        PostVec pv[4];
+        PostOp po = p.post;
+        po.relu = 0;   // the ReLU is folded into the quantizer (enc4_code_relu)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ch = chw + j * 16 + kq * 4;
+            bq[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            pv[j].sc = make_float4(1.f, 1.f, 1.f, 1.f);
+            pv[j].sh = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ch < p.O) {
+                if (p.bias) {
+                    const float4 bb = *reinterpret_cast<const float4*>(p.bias + ch);
+                    bq[j] = make_float4(256.f * ((bb.x / p.s1) / p.s2), 256.f * ((bb.y / p.s1) / p.s2),
+                                        256.f * ((bb.z / p.s1) / p.s2), 256.f * ((bb.w / p.s1) / p.s2));
+                }
+                pv[j] = post_load(p.post, ch);
+            }
+        }
+        const int chs = chw + kq * 16;   // after the transpose: this lane's 16 channels
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int goh = th * TH + wm * MT + i;
+            uint32_t c[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float4 r;
+                r.x = ((acc[i][j][0] + bq[j].x) * p.s1x) * p.s2;
+                r.y = ((acc[i][j][1] + bq[j].y) * p.s1x) * p.s2;
+                r.z = ((acc[i][j][2] + bq[j].z) * p.s1x) * p.s2;
+                r.w = ((acc[i][j][3] + bq[j].w) * p.s1x) * p.s2;
+                r = post_apply_v(r, po, pv[j]);
+                if (p.y_sgn) c[j] = code_sign4(enc4_code<false>(r, r1, lo, hi, smem), r, p.y_fmt);
+                else c[j] = enc4_code_relu(r, r1, lo, hi, smem);
+            }
+            rows_transpose4(c[0], c[1], c[2], c[3]);
+            if (goh < p.Ho && gow < p.Wo && chs < p.O) {
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                *reinterpret_cast<u32x4*>(p.yc + (((size_t)n * p.Ho + goh) * p.Wo + gow) * p.O + chs) = u32x4{c[0], c[1], c[2], c[3]};
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ch = (nt0 + wn * 4 + j) * 16 + kq * 4;
+        if (ch >= p.O) continue;
+        float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias) {
+            const float4 bb = *reinterpret_cast<const float4*>(p.bias + ch);
+            bq = make_float4(256.f * ((bb.x / p.s1) / p.s2), 256.f * ((bb.y / p.s1) / p.s2),
+                             256.f * ((bb.z / p.s1) / p.s2), 256.f * ((bb.w / p.s1) / p.s2));
+        }
+        const PostVec pv = post_load(p.post, ch);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int goh = th * TH + wm * MT + i;
+            if (goh >= p.Ho || gow >= p.Wo) continue;
+            float4 r;
+            r.x = ((acc[i][j][0] + bq.x) * p.s1x) * p.s2;
+            r.y = ((acc[i][j][1] + bq.y) * p.s1x) * p.s2;
+            r.z = ((acc[i][j][2] + bq.z) * p.s1x) * p.s2;
+            r.w = ((acc[i][j][3] + bq.w) * p.s1x) * p.s2;
+            st_stream4<SLFP_NT_DENSE>(p.y + (((size_t)n * p.Ho + goh) * p.Wo + gow) * p.O + ch, post_apply_v(r, p.post, pv));
+        }
+    }
 }
 
 // WM x WN = 8 waves; MT = output rows per wave.  Both operands arrive by LDS-DMA: no VALU work
@@ -294,31 +415,7 @@ __global__ __launch_bounds__(kDnThreads, (MT == 4 || PASSES == 3 ? 2 : 4)) void 
         xb ^= 1;
     }
 
-    // ---- epilogue
-    const int gow = tw * kDnTW + col;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int ch = (nt0 + wn * 4 + j) * 16 + kq * 4;
-        if (ch >= p.O) continue;
-        float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.bias) {
-            const float4 bb = *reinterpret_cast<const float4*>(p.bias + ch);
-            bq = make_float4(256.f * ((bb.x / p.s1) / p.s2), 256.f * ((bb.y / p.s1) / p.s2),
-                             256.f * ((bb.z / p.s1) / p.s2), 256.f * ((bb.w / p.s1) / p.s2));
-        }
-        const PostVec pv = post_load(p.post, ch);
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int goh = th * TH + wm * MT + i;
-            if (goh >= p.Ho || gow >= p.Wo) continue;
-            float4 r;
-            r.x = ((acc[i][j][0] + bq.x) * p.s1x) * p.s2;
-            r.y = ((acc[i][j][1] + bq.y) * p.s1x) * p.s2;
-            r.z = ((acc[i][j][2] + bq.z) * p.s1x) * p.s2;
-            r.w = ((acc[i][j][3] + bq.w) * p.s1x) * p.s2;
-            st_stream4<SLFP_NT_DENSE>(p.y + (((size_t)n * p.Ho + goh) * p.Wo + gow) * p.O + ch, post_apply_v(r, p.post, pv));
-        }
-    }
+    dense_epilogue<MT>(p, acc, smem, n, th, tw, TH, wm, wn, nt0, col, kq);
 }
 
 // ======================================================================================
@@ -470,30 +567,7 @@ __global__ __launch_bounds__(kDnThreads, (MT == 4 ? 2 : 4)) void k_dense3x3(cons
         xb ^= 1;
     }
 
-    const int gow = tw * kDnTW + col;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int ch = (nt0 + wn * 4 + j) * 16 + kq * 4;
-        if (ch >= p.O) continue;
-        float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.bias) {
-            const float4 bb = *reinterpret_cast<const float4*>(p.bias + ch);
-            bq = make_float4(256.f * ((bb.x / p.s1) / p.s2), 256.f * ((bb.y / p.s1) / p.s2),
-                             256.f * ((bb.z / p.s1) / p.s2), 256.f * ((bb.w / p.s1) / p.s2));
-        }
-        const PostVec pv = post_load(p.post, ch);
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int goh = th * TH + wm * MT + i;
-            if (goh >= p.Ho || gow >= p.Wo) continue;
-            float4 r;
-            r.x = ((acc[i][j][0] + bq.x) * p.s1x) * p.s2;
-            r.y = ((acc[i][j][1] + bq.y) * p.s1x) * p.s2;
-            r.z = ((acc[i][j][2] + bq.z) * p.s1x) * p.s2;
-            r.w = ((acc[i][j][3] + bq.w) * p.s1x) * p.s2;
-            st_stream4<SLFP_NT_DENSE>(p.y + (((size_t)n * p.Ho + goh) * p.Wo + gow) * p.O + ch, post_apply_v(r, p.post, pv));
-        }
-    }
+    dense_epilogue<MT>(p, acc, smem, n, th, tw, TH, wm, wn, nt0, col, kq);
 }
 
 // ---- host side: pick the tiling ----------------------------------------------------------
@@ -604,8 +678,25 @@ static int launch_dense_t(DenseParams& p, size_t lds, int planes, hipStream_t st
     return planes == 2 ? launch_dense_tp<WM, WN, MT, 3>(p, lds, stream, 2) : launch_dense_tp<WM, WN, MT, 1>(p, lds, stream, nwb);
 }
 
+// code interface: is there a dense kernel for this layer with code input / output?  (the float32-interface kernel with a decode
+// pre-pass instead of the encode pre-pass and / or the code epilogue: same tilings, same results)
+bool dense_codes_applicable(const slfp_conv2d_desc& d, const ConvPlan& plan, int post_flags, bool y_codes) {
+    if (plan.family != kDenseMfma || plan.repad) return false;
+    if (post_flags & SLFP_POST_LAYEROUT) return false;
+    if (y_codes && d.c_out % 16 != 0) return false;   // a lane stores 16 consecutive channel codes
+    return true;
+}
+
 int launch_dense_mfma(const slfp_conv2d_desc& d, const ConvPlan& plan, const float* x, const void* wblob,
                       const float* bias, const PostOp& post, float* y, void* workspace, hipStream_t stream) {
+    const CodeIo io{false, false, 1.f, kFmtAct8};
+    return launch_dense_mfma_io(d, plan, x, wblob, bias, post, y, workspace, io, stream);
+}
+
+int launch_dense_mfma_io(const slfp_conv2d_desc& d, const ConvPlan& plan, const void* x_any, const void* wblob,
+                         const float* bias, const PostOp& post, void* y_any, void* workspace, const CodeIo& io, hipStream_t stream) {
+    const float* x = reinterpret_cast<const float*>(x_any);
+    float* y = reinterpret_cast<float*>(y_any);
     DenseGeom g;
     const int planes = dense_planes(d, plan.passes);
     if (!dense_choose(d, planes, plan.h_out, plan.w_out, &g)) return fail(SLFP_ERR_UNSUPPORTED, "dense MFMA conv: no tiling fits");
@@ -618,7 +709,13 @@ int launch_dense_mfma(const slfp_conv2d_desc& d, const ConvPlan& plan, const flo
     const int64_t n_chunks16 = d.n * d.h * d.w * (cp / 8);
     const ScaleDiv sd = make_scale_div(d.ka, 4);
     const unsigned egrid = (unsigned)ceil_div(n_chunks16, 256);
-    if (plan.fmt_act == kFmtAct8)
+    if (io.x_codes) {
+        const uint8_t* xc = reinterpret_cast<const uint8_t*>(x_any);
+        if (plan.fmt_act == kFmtAct8)
+            hipLaunchKernelGGL((k_dense_decode<kFmtAct8>), dim3(egrid), dim3(256), 0, stream, xc, xe, xlo, zero_page, n_chunks16, (int)d.c_in, cp);
+        else
+            hipLaunchKernelGGL((k_dense_decode<kFmtSfp7>), dim3(egrid), dim3(256), 0, stream, xc, xe, xlo, zero_page, n_chunks16, (int)d.c_in, cp);
+    } else if (plan.fmt_act == kFmtAct8)
         hipLaunchKernelGGL((k_dense_encode<kFmtAct8>), dim3(egrid), dim3(256), 0, stream, x, xe, xlo, zero_page, n_chunks16, (int)d.c_in, cp, sd);
     else
         hipLaunchKernelGGL((k_dense_encode<kFmtSfp7>), dim3(egrid), dim3(256), 0, stream, x, xe, xlo, zero_page, n_chunks16, (int)d.c_in, cp, sd);
@@ -628,6 +725,16 @@ int launch_dense_mfma(const slfp_conv2d_desc& d, const ConvPlan& plan, const flo
     DenseParams p;
     p.xe = xe; p.xlo = xlo; p.zero_page = zero_page;
     p.w = reinterpret_cast<const _Float16*>(wblob); p.bias = bias; p.y = y; p.post = post;
+    p.yc = nullptr; p.y_sgn = 0; p.y_fmt = kFmtAct8; p.enc_out.valid = 0;
+    if (io.y_codes) {
+        const EncArgs* t = enc_table(io.y_ka, io.y_fmt, kEncCode);
+        if (!t->valid) return fail(SLFP_ERR_UNSUPPORTED, "dense MFMA conv: no code table for the consumer's scale");
+        p.enc_out = *t;
+        p.yc = reinterpret_cast<uint8_t*>(y_any);
+        p.y = nullptr;
+        p.y_sgn = post.relu ? 0 : 1;
+        p.y_fmt = io.y_fmt;
+    }
     p.wlo = p.w + (size_t)d.kh * d.kw * plan.k_pad * plan.n_pad;   // second plane of the blob (float32-equivalent mode)
     p.N = (int)d.n; p.H = (int)d.h; p.W = (int)d.w; p.Cp = cp; p.O = (int)d.c_out;
     p.KH = (int)d.kh; p.KW = (int)d.kw; p.S = d.stride_h; p.ph = d.pad_h; p.pw = d.pad_w;

@@ -60,21 +60,6 @@ __device__ __forceinline__ half8 dec_frag(uint32_t ca, uint32_t cb, const unsign
     return __builtin_bit_cast(half8, u32x4c{pa.x, pa.y, pb.x, pb.y});
 }
 
-// sign handling of the output codes when no ReLU precedes the quantizer: the top bit of every class but exact zero
-__device__ __forceinline__ uint32_t code_sign4(uint32_t d, const float4 x, int fmt_out) {
-    const float xs[4] = {x.x, x.y, x.z, x.w};
-    uint32_t out = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        uint32_t c = (d >> (8 * k)) & 0xFFu;
-        const uint32_t s = (__float_as_uint(xs[k]) >> 24) & 0x80u;
-        c = (c == 1u || xs[k] != xs[k]) ? c : (c | s);
-        out |= c << (8 * k);
-    }
-    if (fmt_out == kFmtSfp7) out = (out & 0x3F3F3F3Fu) | ((out & 0x80808080u) >> 1);
-    return out;
-}
-
 // ======================================================================================
 // k_pwc_stream: W resident in LDS, codes straight into MFMA fragments, 16-pixel work units.
 // ======================================================================================

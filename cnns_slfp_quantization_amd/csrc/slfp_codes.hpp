@@ -194,6 +194,21 @@ __device__ __forceinline__ uint32_t enc4_code_fmt(const float4 x, const float r1
     return d;
 }
 
+// sign handling of the output codes when no ReLU precedes the quantizer: the top bit of every class but exact zero
+__device__ __forceinline__ uint32_t code_sign4(uint32_t d, const float4 x, int fmt_out) {
+    const float xs[4] = {x.x, x.y, x.z, x.w};
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint32_t c = (d >> (8 * k)) & 0xFFu;
+        const uint32_t s = (__float_as_uint(xs[k]) >> 24) & 0x80u;
+        c = (c == 1u || xs[k] != xs[k]) ? c : (c | s);
+        out |= c << (8 * k);
+    }
+    if (fmt_out == kFmtSfp7) out = (out & 0x3F3F3F3Fu) | ((out & 0x80808080u) >> 1);
+    return out;
+}
+
 // ---- 4 x 4 dword transpose across the four 16-lane rows of a wave --------------------------------------------------
 // in:  row r (lanes 16r..16r+15) holds a[i] = M[r][i];  out: row r holds a[i] = M[i][r].
 // Two v_permlane32_swap (rows {0,1} <-> {2,3}) and two v_permlane16_swap (odd <-> even rows): 4 VALU instructions for

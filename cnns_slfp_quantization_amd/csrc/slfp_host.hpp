@@ -142,6 +142,10 @@ bool dense_mfma_applicable(const slfp_conv2d_desc& d, int passes);
 size_t dense_mfma_workspace_bytes(const slfp_conv2d_desc& d, int passes);
 int launch_dense_mfma(const slfp_conv2d_desc& d, const ConvPlan& p, const float* x, const void* wblob,
                       const float* bias, const PostOp& post, float* y, void* workspace, hipStream_t stream);
+// the same with 1-byte codes in and / or out (x_any: float32 or uint8 codes of QA(x / d.ka); y_any: float32 or uint8 codes)
+bool dense_codes_applicable(const slfp_conv2d_desc& d, const ConvPlan& p, int post_flags, bool y_codes);
+int launch_dense_mfma_io(const slfp_conv2d_desc& d, const ConvPlan& p, const void* x_any, const void* wblob, const float* bias,
+                         const PostOp& post, void* y_any, void* workspace, const CodeIo& io, hipStream_t stream);
 // codes: `w_oihw` points at 1-byte extended weight codes (slfp_encode_f32 | SLFP_FMT_EXT) instead of float32 weights
 int launch_prepare_weights(const slfp_conv2d_desc& d, const ConvPlan& p, const float* w_oihw, void* wprep,
                            float* weight_q_oihw, hipStream_t stream, bool codes = false);

@@ -173,7 +173,8 @@ int slfp_dwpw_fwd(const slfp_conv2d_desc* dw, const slfp_conv2d_desc* pw, const 
  * slfp_encode_f32).  Both tensors are NHWC; x, y and wprep 16-byte aligned; wprep is the blob of
  * slfp_conv2d_prepare_weights for the same descriptor.  Supported: 3x3 depthwise (x_codes), 1x1 (x_codes; C_in a
  * multiple of 32, C_out of 16 with y_codes), and the 3x3 stride-2 RGB stem -> 32 channels (float32 in, y_codes):
- * every layer of nets_imgnet/mobilenetv1.py:43-57.  slfp_conv2d_codes_supported answers 1 / 0 without device work. */
+ * every layer of nets_imgnet/mobilenetv1.py:43-57; dense k x k layers through slfp_conv2d_fwd_codes_ws (below).
+ * slfp_conv2d_codes_supported answers 1 / 0 without device work. */
 typedef struct slfp_conv2d_io {
     int32_t x_codes;  /* 0: x is float32 (as slfp_conv2d_fwd); 1: x is uint8 codes of QA(. / d->ka), format of d->qbits */
     int32_t y_codes;  /* 0: y is float32; 1: y receives uint8 codes of QA(out / y_ka) in the format of y_qbits        */
@@ -185,6 +186,13 @@ int slfp_conv2d_codes_supported(const slfp_conv2d_desc* d, const slfp_conv2d_io*
 int slfp_conv2d_fwd_codes(const slfp_conv2d_desc* d, const slfp_conv2d_io* io, const void* x, const void* wprep,
                           const float* bias, const float* post_scale, const float* post_shift, int relu, void* y,
                           void* stream);
+/* The same with a workspace, for the layers whose float32 form needs one: dense k x k convolutions on the matrix cores
+ * (VGG-16 / ResNet-50 3x3, SqueezeNet expand3x3; x_codes and / or y_codes; C_out a multiple of 16 with y_codes).  `workspace`:
+ * slfp_conv2d_workspace_bytes(d) bytes, 16-byte aligned; may be NULL for the layers slfp_conv2d_fwd_codes takes.  The codes
+ * are decoded into the same fp16 operand copy the float32 interface builds from its input: results are bit-identical. */
+int slfp_conv2d_fwd_codes_ws(const slfp_conv2d_desc* d, const slfp_conv2d_io* io, const void* x, const void* wprep,
+                             const float* bias, const float* post_scale, const float* post_shift, int relu, void* y,
+                             void* workspace, void* stream);
 /* Self-check of the producer side: sweeps ALL 2^32 float32 inputs on the device; out3[0] = inputs whose table-driven code
  * (signed variant) differs from slfp_encode_f32(.., fmt | SLFP_FMT_EXT), out3[1] = the same for the unsigned variant a
  * producer with a ReLU epilogue runs (inputs >= +0 and -0), out3[2] = code bytes whose decode-table entries (float32 and

@@ -92,6 +92,14 @@ class _Layer:
         assert L.slfp_conv2d_codes_supported(ctypes.byref(self.d), ctypes.byref(io), 0, 1 if self.relu else 0) == 1, \
             (self.kernel, self.s, x_codes, y_ka)
         y = torch.empty(self.out_shape(), dtype=torch.float32 if y_ka is None else torch.uint8, device=x.device)
+        ws_n = L.slfp_conv2d_workspace_bytes(ctypes.byref(self.d))
+        if ws_n:   # dense k x k layers: the fp16 operand copy (slfp_conv2d_fwd_codes_ws)
+            ws = torch.empty(ws_n, dtype=torch.uint8, device=x.device)
+            lib.check(L.slfp_conv2d_fwd_codes_ws(ctypes.byref(self.d), ctypes.byref(io), x.data_ptr(), self.blob.data_ptr(), None,
+                                                 self.scale.data_ptr() if self.scale is not None else None,
+                                                 self.shift.data_ptr() if self.shift is not None else None,
+                                                 1 if self.relu else 0, y.data_ptr(), ws.data_ptr(), _stream()))
+            return y
         lib.check(L.slfp_conv2d_fwd_codes(ctypes.byref(self.d), ctypes.byref(io), x.data_ptr(), self.blob.data_ptr(), None,
                                           self.scale.data_ptr() if self.scale is not None else None,
                                           self.shift.data_ptr() if self.shift is not None else None,
@@ -168,6 +176,55 @@ def test_each_mobilenet_layer_on_codes_is_bit_identical_to_the_float32_interface
         yc = lay.fwd_codes(lib, xc, True, ka_next, qbits)      # codes in, codes out
         bad = int((yc != codes_ref).sum())
         assert bad == 0, (lay.kernel, i, "producer", bad, yc.numel())
+
+
+@pytest.mark.parametrize("qbits", [8, 7])
+def test_dense_layers_on_codes_are_bit_identical_to_the_float32_interface(lib, dev, qbits):
+    """The dense k x k family (VGG-16 / ResNet-50 3x3, SqueezeNet expand3x3, a stride-2 and a 5x5 case) through
+    slfp_conv2d_fwd_codes_ws: codes in -> the same float32 output bit for bit (the decode pre-pass builds the same fp16 operand
+    copy as the encode pre-pass); float32 or codes in -> codes out == slfp_encode_f32(float32 output, Ka_next); with and
+    without a ReLU in front of the output quantizer; a workspace is required."""
+    from cnns_slfp_quantization_amd.layer_specs import ConvSpec
+    gen = torch.Generator(device=dev).manual_seed(77 + qbits)
+    fmt = lib.FMT_ACT8 if qbits == 8 else lib.FMT_SFP7
+    L = lib.load()
+    shapes = [  # c_in, c_out, k, stride, pad, h
+        (64, 64, 3, 1, 1, 28), (128, 256, 3, 1, 1, 14), (256, 256, 3, 1, 1, 9), (64, 256, 3, 1, 1, 13),
+        (128, 128, 3, 2, 1, 15), (48, 192, 5, 1, 2, 13), (512, 512, 3, 1, 1, 7), (96, 80, 3, 1, 1, 11)]
+    for ci, co, k, st, pd, h in shapes:
+        ho = (h + 2 * pd - k) // st + 1
+        s = ConvSpec(c_in=ci, c_out=co, k=(k, k), stride=(st, st), pad=(pd, pd), groups=1, bias=False, h=h, w=h, h_out=ho, w_out=ho,
+                     Ka=0.37, Kw=0.021)
+        for relu in (True, False):
+            lay = _Layer(lib, s, 3, qbits, dev, gen, post=True, relu=relu)
+            assert lay.kernel.startswith("dense_mfma"), lay.kernel
+            x = _synthetic_input(s, 3, dev, gen, signed=not relu)
+            y_ref = lay.fwd_f32(lib, x)
+            ka_next = 0.2345
+            codes_ref = _encode(lib, y_ref, ka_next, fmt)
+            xc = _encode(lib, x, s.Ka, fmt)
+            y = lay.fwd_codes(lib, xc, True)
+            assert torch.equal(y.view(torch.int32), y_ref.view(torch.int32)), (ci, co, k, st, relu, "consumer", float((y - y_ref).abs().max()))
+            for src, is_codes in ((x, False), (xc, True)):
+                yc = lay.fwd_codes(lib, src, is_codes, ka_next, qbits)
+                bad = int((yc != codes_ref).sum())
+                assert bad == 0, (ci, co, k, st, relu, "producer", is_codes, bad, yc.numel())
+    # no workspace -> refused, nothing launched
+    s = ConvSpec(c_in=64, c_out=64, k=(3, 3), stride=(1, 1), pad=(1, 1), groups=1, bias=False, h=8, w=8, h_out=8, w_out=8, Ka=0.37, Kw=0.021)
+    lay = _Layer(lib, s, 2, qbits, dev, gen)
+    io = lib.ConvIo(x_codes=1, y_codes=0, y_ka=1.0, y_qbits=8)
+    xc = torch.zeros((2, 8, 8, 64), dtype=torch.uint8, device=dev)
+    y = torch.empty((2, 8, 8, 64), device=dev)
+    rc = L.slfp_conv2d_fwd_codes(ctypes.byref(lay.d), ctypes.byref(io), xc.data_ptr(), lay.blob.data_ptr(), None, None, None, 0,
+                                 y.data_ptr(), _stream())
+    assert rc == lib.ERR_BAD_ARG, rc
+    # code output needs C_out % 16 == 0
+    s = ConvSpec(c_in=64, c_out=72, k=(3, 3), stride=(1, 1), pad=(1, 1), groups=1, bias=False, h=8, w=8, h_out=8, w_out=8, Ka=0.37, Kw=0.021)
+    d = _desc(lib, s, 2, qbits)
+    io = lib.ConvIo(x_codes=1, y_codes=1, y_ka=0.5, y_qbits=qbits)
+    assert L.slfp_conv2d_codes_supported(ctypes.byref(d), ctypes.byref(io), 0, 1) == 0
+    io = lib.ConvIo(x_codes=1, y_codes=0, y_ka=1.0, y_qbits=qbits)
+    assert L.slfp_conv2d_codes_supported(ctypes.byref(d), ctypes.byref(io), 0, 1) == 1
 
 
 def test_codes_without_relu_carry_the_sign(lib, dev):

@@ -1242,6 +1242,27 @@ def _build_r3(net, dev, qbits=None, channels_last=True):
     return m, x, gold, dict(m.named_modules())[tap]
 
 
+def test_vgg16_code_links_run_on_the_dense_kernels_and_are_bit_identical(dev):
+    """nets_cifar/vgg16.py:30-92 (the fixture's net) after fuse_bn_relu + link_codes: inside every nn.Sequential stage the
+    hand-overs conv -> conv become 1-byte codes on the dense 3x3 kernels (slfp_conv2d_fwd_codes_ws: decode pre-pass / code
+    epilogue; the MaxPool2d at the end of a stage keeps float32); the logits do not change by a single bit."""
+    from cnns_slfp_quantization_amd import fusion
+    import utils.conv2d_func as cf
+    m, x, gold, tap = _build_r3("vgg16", dev)
+    convs = [c for c in m.modules() if isinstance(c, torch.nn.Conv2d)]
+    with torch.no_grad():
+        assert fusion.fuse_bn_relu(m) == 13
+        y_fused = m(x)
+        n = fusion.link_codes(m, x)
+        assert n >= 7, n   # 1 + 2 + 2 + 2 inside stages 2-5 (+ stage 1 if the 3-channel stem can hand over codes)
+        y_codes = m(x)
+        kernels = [c._last_kernel for c in convs]
+    assert sum("codes_in" in k for k in kernels) == n and sum("codes_out" in k for k in kernels) == n, kernels
+    assert any(k.startswith("dense_mfma") and "codes_in" in k and "codes_out" in k for k in kernels), kernels
+    assert torch.equal(y_codes.view(torch.int32), y_fused.view(torch.int32)), float((y_codes - y_fused).abs().max())
+    assert fusion.unlink_codes(m) == n
+
+
 # (max-rel, l2) bars on the logits and on the mid-network activation.  Chained layers amplify single code flips (SURVEY
 # section 7), deeper nets more.  The yardstick is the reference against ITSELF with another summation order (the fixture's
 # net re-run on the CPU with oneDNN disabled, round 3): ResNet-50 logits move 5.1e-2 / 4.9e-2, VGG-16 2.8e-2 / 3.1e-2; the
