@@ -114,15 +114,17 @@ class Layer:
 FAMILY_KERNELS = {"dw3x3_nhwc": ("k_dw3x3",), "stem_nhwc": ("k_stem", "k_stem_fixed"), "direct_nhwc": ("k_direct",),
                   "pw_mfma_f16x1": ("k_pw_stream", "k_pw_tiled"), "pw_mfma_f16x3": ("k_pw_stream", "k_pw_tiled"),
                   "pw_mfma_f16_exact": ("k_pw_stream", "k_pw_tiled"),
-                  "dense_mfma_f16x1": ("k_dense_mfma", "k_dense_encode"), "dense_mfma_f16x3": ("k_dense_mfma", "k_dense_encode"), "dense_mfma_f16_exact": ("k_dense_mfma", "k_dense_encode"),
+                  "dense_mfma_f16x1": ("k_dense_mfma", "k_dense3x3", "k_dense_encode"), "dense_mfma_f16x3": ("k_dense_mfma", "k_dense_encode"),
+                  "dense_mfma_f16_exact": ("k_dense_mfma", "k_dense3x3", "k_dense_encode"),
                   "stem_mfma_f16x1": ("k_stem_mfma", "k_stem_im2row"), "stem_mfma_f16_exact": ("k_stem_mfma", "k_stem_im2row"),
                   "stem_small_mfma_f16x1": ("k_stem_small",), "stem_small_mfma_f16_exact": ("k_stem_small",),
                   # the code path (run_codes_config): families of slfp_conv2d_fwd_codes
                   "stem_codes": ("k_stem_mx", "k_stem_fixed"), "dw3x3_codes": ("k_dwc",),
-                  "pw_mfma_codes": ("k_pwc_stream", "k_pwc_tiled", "k_pwc_slice")}
+                  "pw_mfma_codes": ("k_pwc_stream", "k_pwc_tiled", "k_pwc_slice"),
+                  "dense_mfma_codes": ("k_dense_mfma", "k_dense3x3", "k_dense_decode", "k_dense_encode")}
 
 
-PREPASS_KERNELS = ("k_dense_encode", "k_stem_im2row")
+PREPASS_KERNELS = ("k_dense_encode", "k_dense_decode", "k_stem_im2row")
 
 
 def pmc_traffic(family, net, batch):
@@ -464,40 +466,72 @@ def run_config(L, net, batch, qbits, passes, steps, warmup, dev, rank, world, po
 
 
 def run_codes_config(L, net, batch, qbits, steps, warmup, dev):
-    """The same 27 layers as ONE chain of 1-byte activation codes (second half; slfp_conv2d_fwd_codes):
-    every layer with the fused BatchNorm + ReLU epilogue, the stem reading float32 images and writing the next layer's
-    codes, every other layer reading codes (of its own synthetic input, resident in HBM) and writing codes, the last one
-    writing float32.  Algorithmic bytes: 1 B per activation element on a code side, 4 B on a float32 side, weights once
+    """The same conv layers with 1-byte activation codes on every hand-over fusion.link_codes can make (SURVEY 8f rank 1,
+    second half; slfp_conv2d_fwd_codes_ws): every layer with the fused BatchNorm + ReLU epilogue; MobileNetV1: ONE chain, the stem
+    reading float32 images and writing the next layer's codes, every other layer reading codes (of its own synthetic input,
+    resident in HBM) and writing codes, the last one writing float32; VGG-16: the conv -> conv hand-overs inside a stage.  Algorithmic bytes: 1 B per activation element on a code side, 4 B on a float32 side, weights once
     per batch.  Bit-identical to the float32 interface (tests/test_gpu_codes.py); single-pass MFMA mode."""
     specs = layer_specs.conv_layers(net)
     gen = torch.Generator(device=dev).manual_seed(4321)
     stream = torch.cuda.current_stream().cuda_stream
     fmt = (_lib.FMT_ACT8 if qbits == 8 else _lib.FMT_SFP7) | _lib.FMT_EXT
+
+    def direct(i):
+        """Does layer i's (fused BN + ReLU) output feed layer i+1 directly, as fusion.link_codes requires?  MobileNetV1: always
+        (nets_imgnet/mobilenetv1.py:43-57); VGG-16: inside a stage (a MaxPool2d halves the size between stages,
+        nets_cifar/vgg16.py:30-92; it keeps float32)."""
+        if i < 0 or i + 1 >= len(specs):
+            return False
+        a, b = specs[i], specs[i + 1]
+        return a.c_out == b.c_in and a.h_out == b.h and a.w_out == b.w
+
+    # a hand-over becomes codes where both kernels exist: decided left to right, as link_codes does
+    x_codes = [False] * len(specs)
+    y_codes = [False] * len(specs)
+    descs = []
+    for s in specs:
+        descs.append(_lib.ConvDesc(n=batch, c_in=s.c_in, h=s.h, w=s.w, c_out=s.c_out, kh=s.k[0], kw=s.k[1], stride_h=s.stride[0],
+                                   stride_w=s.stride[1], pad_h=s.pad[0], pad_w=s.pad[1], dil_h=1, dil_w=1, groups=s.groups,
+                                   x_layout=_lib.LAYOUT_NHWC, y_layout=_lib.LAYOUT_NHWC, qbits=qbits, ka=float(np.float32(s.Ka)),
+                                   kw_scale=float(np.float32(s.Kw)), mfma_passes=_lib.MFMA_F16X1, reserved=0))
+
+    def ok(i, xin, yout):
+        io = _lib.ConvIo(x_codes=1 if xin else 0, y_codes=1 if yout else 0,
+                         y_ka=float(np.float32(specs[i + 1].Ka)) if yout else 1.0, y_qbits=qbits)
+        return bool(L.slfp_conv2d_codes_supported(ctypes.byref(descs[i]), ctypes.byref(io), 0, 1))
+
+    for i in range(len(specs) - 1):
+        if direct(i) and ok(i, x_codes[i], True) and ok(i + 1, True, False):
+            y_codes[i] = x_codes[i + 1] = True
+    if not any(y_codes):
+        return None
     layers = []
     for i, s in enumerate(specs):
         l = Layer(L, s, batch, dev, _lib.MFMA_F16X1, gen, qbits, post=True)
         l.prepare(L, stream)
-        last = i == len(specs) - 1
-        first = s.c_in == 3
-        l.io = _lib.ConvIo(x_codes=0 if first else 1, y_codes=0 if last else 1,
-                           y_ka=float(np.float32(specs[i + 1].Ka if not last else 1.0)), y_qbits=qbits)
-        l.codes_ok = bool(L.slfp_conv2d_codes_supported(ctypes.byref(l.desc), ctypes.byref(l.io), 0, 1))
-        if not l.codes_ok:
-            return None
-        if not first:
+        l.io = _lib.ConvIo(x_codes=1 if x_codes[i] else 0, y_codes=1 if y_codes[i] else 0,
+                           y_ka=float(np.float32(specs[i + 1].Ka)) if y_codes[i] else 1.0, y_qbits=qbits)
+        l.on_codes = x_codes[i] or y_codes[i]
+        if x_codes[i]:
             xc = torch.empty(l.x.shape, dtype=torch.uint8, device=dev)
             _lib.check(L.slfp_encode_f32(l.x.data_ptr(), xc.data_ptr(), l.x.numel(), float(l.desc.ka), fmt, stream))
             l.x = xc
-        if not last:
+        if y_codes[i]:
             l.y = torch.empty(l.y.shape, dtype=torch.uint8, device=dev)
-        l.cbytes = batch * (s.in_elems * (4 if first else 1) + s.out_elems * (4 if last else 1)) + 4 * s.w_elems
-        l.family = ("stem" if first else ("dw3x3" if s.groups > 1 else "pw_mfma")) + "_codes"
+        l.cbytes = batch * (s.in_elems * (1 if x_codes[i] else 4) + s.out_elems * (1 if y_codes[i] else 4)) + 4 * s.w_elems
+        base = "stem" if s.c_in == 3 else ("dw3x3" if s.groups > 1 else ("pw_mfma" if s.k == (1, 1) else "dense_mfma"))
+        l.family = base + ("_codes" if l.on_codes else "_float32")
         layers.append(l)
     torch.cuda.synchronize()
 
     def run(l):
-        rc = L.slfp_conv2d_fwd_codes(ctypes.byref(l.desc), ctypes.byref(l.io), l.x.data_ptr(), l.blob.data_ptr(), None,
-                                     l.post[0].data_ptr(), l.post[1].data_ptr(), 1, l.y.data_ptr(), stream)
+        if not l.on_codes:   # a layer with float32 on both sides (VGG-16's first stage): the float32 interface
+            l.run(L, stream)
+            return
+        rc = L.slfp_conv2d_fwd_codes_ws(ctypes.byref(l.desc), ctypes.byref(l.io), l.x.data_ptr(), l.blob.data_ptr(),
+                                        l.bias.data_ptr() if l.bias is not None else None,
+                                        l.post[0].data_ptr(), l.post[1].data_ptr(), 1, l.y.data_ptr(),
+                                        l.ws.data_ptr() if l.ws is not None else None, stream)
         if rc != 0:
             _lib.check(rc)
 
@@ -659,11 +693,15 @@ def main():
                     other[net] = {"batch": b, "qbits": q, "value": r["value"], "unit": "images/sec", "ms_per_step": r["ms_per_step"],
                                   "hbm_roofline_frac_whole_path": r["hbm_roofline_frac_whole_path"], "roofline": r["roofline"],
                                   "kernels": r["kernels"]}
+                    if net == "vgg16_224":   # the conv -> conv hand-overs inside VGG-16's stages as 1-byte codes (dense kernels)
+                        cp = run_codes_config(L, net, b, q, 3, 1, dev)
+                        if cp:
+                            other[net]["codes_path"] = {k: cp[k] for k in ("value", "unit", "ms_per_step", "algorithmic_bytes_per_image", "kernels")}
                 except Exception as e:  # a secondary measurement must not take the headline line down
                     other[net] = {"batch": b, "qbits": q, "error": str(e)[:200]}
             out["other_configs"] = other
             out["codec"] = codec_bench(L, dev)
-        if args.net == "mobilenetv1_imagenet224" and args.passes in (0, 1) and not args.post:
+        if args.net in ("mobilenetv1_imagenet224", "vgg16_224") and args.passes in (0, 1) and not args.post:
             try:   # secondary measurement: the same layers chained through 1-byte codes
                 cp = run_codes_config(L, args.net, batch, args.qbits, args.steps, args.warmup, dev)
                 if cp:
