@@ -391,11 +391,111 @@ def link_codes(model, example_input=None):
     return n_links
 
 
+def link_codes_traced(model, example_input):
+    """link_codes for blocks that wire their layers by hand in forward() (the reference's ResNet-50 Bottleneck,
+    nets_imgnet/resnet50.py:74-100: conv1 -> bn1 -> relu -> conv2 -> bn2 -> relu -> conv3 -> bn3 -> (+ identity) -> relu, with ONE
+    shared nn.ReLU).  One forward records the tensors: a Conv2d_Q `b` whose input IS the output of a Conv2d_Q `a` -- directly or
+    through nn.Identity (a folded BatchNorm, fuse_named_bn) and / or an nn.ReLU module -- is a candidate; `a` gets the ReLU
+    folded into its epilogue (the module's own relu() then runs on the uint8 codes, where it is the identity) and writes `b`'s
+    codes.  Links are made only where libslfp_hip has both kernels (slfp_conv2d_codes_supported), never for a producer with
+    two consumers, and the whole set is VERIFIED: the linked model must reproduce the unlinked output bit for bit on
+    `example_input`, otherwise (a functional use of the tensor that hooks cannot see, e.g. a torch.cat) everything is rolled
+    back and 0 is returned.  Inference only; unlink_codes undoes it.  Returns the number of links."""
+    import ctypes as _ct
+    from . import _lib
+    from .conv2d_func import _f32, _scalar_scale, options
+    conv_io, relu_io, order, keep = {}, [], [], []
+    hooks = []
+    for m in model.modules():
+        if _is_conv_q(m):
+            def _rec(mod, inp, out):
+                conv_io[mod] = (inp[0], out)
+                order.append(mod)
+                keep.append((inp[0], out))
+            hooks.append(m.register_forward_hook(_rec))
+        elif isinstance(m, nn.ReLU):
+            def _rec_relu(mod, inp, out):   # (returns None: a hook's return value would replace the module's output)
+                relu_io.append((inp[0], out))
+                keep.append((inp[0], out))
+            hooks.append(m.register_forward_hook(_rec_relu))
+    try:
+        with torch.no_grad():
+            y0 = model(example_input)
+    finally:
+        for h in hooks:
+            h.remove()
+    if len(order) != len(set(order)):
+        return 0   # a module that runs twice per forward has no single producer / consumer
+    producer = {id(out): c for c, (_, out) in conv_io.items()}
+    relu_src = {id(out): inp for inp, out in relu_io}
+
+    def eligible(m):
+        return (m.q_bit in (8, 7) and not m.training and isinstance(m.padding, tuple) and m._code_out is None
+                and (m.bias is None or getattr(m, "_scaled_bias", False)) and not (m._post is not None and (int(m._post[2]) & 2)))
+
+    def supported(m, x_codes, out, flags):
+        xin = conv_io[m][0]
+        if xin.dim() != 4:
+            return False
+        n, c, h, w = xin.shape
+        d = _lib.ConvDesc(n=n, c_in=c, h=h, w=w, c_out=m.out_channels, kh=m.weight.shape[2], kw=m.weight.shape[3],
+                          stride_h=m.stride[0], stride_w=m.stride[1], pad_h=m.padding[0], pad_w=m.padding[1], dil_h=m.dilation[0],
+                          dil_w=m.dilation[1], groups=m.groups, x_layout=_lib.LAYOUT_NHWC, y_layout=_lib.LAYOUT_NHWC, qbits=m.q_bit,
+                          ka=_f32(_scalar_scale(m.Ka, "Ka")), kw_scale=_f32(_scalar_scale(m.Kw, "Kw")),
+                          mfma_passes=options.mfma_passes, reserved=0)
+        io = _lib.ConvIo(x_codes=1 if x_codes else 0, y_codes=1 if out is not None else 0,
+                         y_ka=_f32(out[0]) if out is not None else 1.0, y_qbits=int(out[1]) if out is not None else 8)
+        return bool(_lib.load().slfp_conv2d_codes_supported(_ct.byref(d), _ct.byref(io), 1 if m.bias is not None else 0, flags))
+
+    cand = {}
+    for b in order:
+        t, via_relu = conv_io[b][0], False
+        if id(t) in relu_src:
+            t, via_relu = relu_src[id(t)], True
+        a = producer.get(id(t))
+        if a is None or a is b or not eligible(a) or not eligible(b):
+            continue
+        cand.setdefault(a, []).append((b, via_relu))
+    made, reads_codes = [], set()
+    for a in order:   # execution order: whether `a` itself reads codes is known when its own link is decided
+        if a not in cand or len(cand[a]) != 1:
+            continue
+        b, via_relu = cand[a][0]
+        flags = (int(a._post[2]) if a._post is not None else 0) | (1 if via_relu else 0)
+        out = (float(_scalar_scale(b.Ka, "Ka")), int(b.q_bit))
+        bflags = int(b._post[2]) if b._post is not None else 0
+        if not supported(a, a in reads_codes, out, flags) or not supported(b, True, None, bflags):
+            continue
+        made.append((a, a._post))
+        a._post = ((a._post[0], a._post[1]) if a._post is not None else (None, None)) + (flags,)
+        a._code_out = out
+        a._pre_link_post = made[-1][1]
+        reads_codes.add(b)
+    if not made:
+        return 0
+    ok = False
+    try:
+        with torch.no_grad():
+            y1 = model(example_input)
+        ok = y1.dtype == y0.dtype and torch.equal(y1, y0)
+    except Exception:
+        ok = False
+    if not ok:
+        for a, post in made:
+            a._post, a._code_out = post, None
+            del a._pre_link_post
+        return 0
+    return len(made)
+
+
 def unlink_codes(model):
-    """Undo link_codes."""
+    """Undo link_codes / link_codes_traced."""
     n = 0
     for m in model.modules():
         if _is_conv_q(m) and m._code_out is not None:
             m._code_out = None
+            if hasattr(m, "_pre_link_post"):
+                m._post = m._pre_link_post
+                del m._pre_link_post
             n += 1
     return n

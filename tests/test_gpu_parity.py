@@ -1263,6 +1263,62 @@ def test_vgg16_code_links_run_on_the_dense_kernels_and_are_bit_identical(dev):
     assert fusion.unlink_codes(m) == n
 
 
+def test_resnet50_traced_code_links_are_verified_and_bit_identical(dev):
+    """nets_imgnet/resnet50.py:74-100 (Bottlenecks wired by hand, one shared nn.ReLU): fuse_named_bn, then
+    fusion.link_codes_traced -- every 3x3 -> 1x1 hand-over inside a block becomes codes (the block's first 1x1 reads float32:
+    there is no float32 -> codes pointwise kernel), the residual adds and the stem keep float32; the linked net reproduces
+    the unlinked logits bit for bit (link_codes_traced verifies that itself and rolls back otherwise)."""
+    from cnns_slfp_quantization_amd import fusion
+    m, x, gold, tap = _build_r3("resnet50", dev)
+    convs = [c for c in m.modules() if isinstance(c, torch.nn.Conv2d)]
+    with torch.no_grad():
+        assert fusion.fuse_named_bn(m, example_input=x) == 49
+        y_fused = m(x)
+        n = fusion.link_codes_traced(m, x)
+        assert n == 16, n
+        y_codes = m(x)
+        kernels = [c._last_kernel for c in convs]
+        assert torch.equal(y_codes.view(torch.int32), y_fused.view(torch.int32))
+        assert sum("codes_out" in k for k in kernels) == 16 and sum("codes_in" in k for k in kernels) == 16, kernels
+        assert all(k.startswith("dense_mfma") for k in kernels if "codes_out" in k), kernels
+        assert fusion.unlink_codes(m) == 16
+        y_back = m(x)
+    assert torch.equal(y_back.view(torch.int32), y_fused.view(torch.int32))
+
+
+def test_traced_code_links_roll_back_when_a_tensor_has_a_use_hooks_cannot_see(dev):
+    """A block that ALSO concatenates the producer's output in its forward() (a functional use no module hook records): the
+    candidate link passes the wiring checks, fails link_codes_traced's own bit-for-bit verification and is rolled back."""
+    from cnns_slfp_quantization_amd import fusion
+    import utils.conv2d_func as cf
+
+    class Blk(torch.nn.Module):
+        def __init__(self, leak):
+            super().__init__()
+            C = cf.conv2d_Q(q_bit=8, Kw=0.02, Ka=0.3)
+            self.a = C(32, 32, 3, 0.02, 0.3, 1, 1)
+            self.b = C(32, 64, 1, 0.02, 0.25, 1, 0)
+            self.relu = torch.nn.ReLU()
+            self.leak = leak
+
+        def forward(self, x):
+            h = self.relu(self.a(x))
+            y = self.b(h)
+            return torch.cat([y, h], 1) if self.leak else y
+
+    torch.manual_seed(5)
+    x = torch.randn(2, 32, 12, 12, device=dev).contiguous(memory_format=torch.channels_last)
+    for leak, want in ((True, 0), (False, 1)):
+        m = Blk(leak).to(dev).eval().to(memory_format=torch.channels_last)
+        with torch.no_grad():
+            m.a.weight.mul_(0.5); m.b.weight.mul_(0.5)
+            y0 = m(x)
+            assert fusion.link_codes_traced(m, x) == want
+            assert (m.a._code_out is not None) == bool(want)
+            assert torch.equal(m(x), y0)
+            assert fusion.unlink_codes(m) == want and m.a._post is None
+
+
 # (max-rel, l2) bars on the logits and on the mid-network activation.  Chained layers amplify single code flips (SURVEY
 # section 7), deeper nets more.  The yardstick is the reference against ITSELF with another summation order (the fixture's
 # net re-run on the CPU with oneDNN disabled, round 3): ResNet-50 logits move 5.1e-2 / 4.9e-2, VGG-16 2.8e-2 / 3.1e-2; the
