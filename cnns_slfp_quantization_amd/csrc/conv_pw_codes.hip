@@ -388,49 +388,66 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 4) void k_pwc_ti
 
     const int KT = p.KS >> 1;  // 64-deep stages
     const int ntile0 = (int)nb * (BN / 16) + wn * NT;
-    const _Float16* wbase[NT];
+    // W fragments by buffer loads: descriptor + per-tile byte offsets in scalar registers (the wave index is made uniform for
+    // the compiler), ONE vector register of address (lane * 16) for all of them -- the double buffer below needs the registers
+    const int wn_u = __builtin_amdgcn_readfirstlane(wn);
+    const int ntile0u = (int)nb * (BN / 16) + wn_u * NT;
+    const uint64_t wbytes = (uint64_t)p.n_tiles * p.KS * 1024;
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.whi), 0,
+                                                                        (uint32_t)(wbytes > 0xFFFFFFFFull ? 0xFFFFFFFFull : wbytes), 0x00020000);
+    uint32_t wsoff[NT];   // scalar
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        const int nt = ntile0 + j < p.n_tiles ? ntile0 + j : p.n_tiles - 1;
-        wbase[j] = p.whi + (size_t)nt * p.KS * 512 + (size_t)lane * 8;
+        const int nt = ntile0u + j < p.n_tiles ? ntile0u + j : p.n_tiles - 1;
+        wsoff[j] = (uint32_t)nt * (uint32_t)p.KS * 1024u;
     }
-    half8 wh[NT];
-    auto load_w = [&](int kstep) {
+    const uint32_t wvoff = (uint32_t)lane * 16u;
+    // W fragments double-buffered by k-step (a stage of codes is 2 registers per lane, so there is room -- the float32-interface
+    // kernel has none): W(2t+1) is requested at the top of stage t, BEFORE the X loads of stage t+2, W(2t+2) once the first
+    // k-step's MFMAs have read its buffer.  Every vmcnt wait is then for loads issued at least half a stage earlier, and no W
+    // wait sits behind X loads that have not been waited for already (loads retire in order through one counter).
+    half8 whb[2][NT];
+    auto load_w = [&](int kstep, int b) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j) wh[j] = *reinterpret_cast<const half8*>(wbase[j] + (size_t)kstep * 512);
+        for (int j = 0; j < NT; ++j) {
+            typedef uint32_t u32x4w __attribute__((ext_vector_type(4)));
+            const u32x4w v = __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff, wsoff[j] + (uint32_t)kstep * 1024u, 0);
+            whb[b][j] = __builtin_bit_cast(half8, v);
+        }
     };
-    auto mfma_step = [&](int buf, int ks) {
+    auto mfma_step = [&](int buf, int ks, int b) {
         const unsigned char* hi = xs + (size_t)buf * XBYTES;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int row = (wm * MT + i) * 16 + col;
             const half8 xh = *reinterpret_cast<const half8*>(hi + lds_x_off(row, ks * 4 + kq));
 #pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], xh, acc[i][j], 0, 0, 0);
+            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whb[b][j], xh, acc[i][j], 0, 0, 0);
         }
     };
 
     load_stage(0);
     __syncthreads();  // tables visible
     decode_store(0);
+    load_w(0, 0);
     load_stage(KT > 1 ? 1 : 0);
     __syncthreads();
     for (int t = 0; t + 1 < KT; ++t) {  // branch-free body
         const int buf = t & 1;
-        load_w(t * 2);
+        load_w(t * 2 + 1, 1);
         decode_store(buf ^ 1);
         load_stage(t + 2 < KT ? t + 2 : KT - 1);
-        mfma_step(buf, 0);
-        load_w(t * 2 + 1);
-        mfma_step(buf, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step(buf, 0, 0);
+        load_w(t * 2 + 2, 0);
+        mfma_step(buf, 1, 1);
         __syncthreads();
     }
     {
         const int t = KT - 1, buf = t & 1;
-        load_w(t * 2);
-        mfma_step(buf, 0);
-        load_w(t * 2 + 1);
-        mfma_step(buf, 1);
+        load_w(t * 2 + 1, 1);
+        mfma_step(buf, 0, 0);
+        mfma_step(buf, 1, 1);
     }
 
     const int n_lo = (int)nb * BN;
