@@ -423,12 +423,24 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 4) void k_pw_til
     const int KT = p.KS >> 1;  // 64-deep stages
     const int ntile0 = (int)nb * (BN / 16) + wn * NT;
     const size_t wplane = (size_t)(p.wlo - p.whi);
-    const _Float16* wbase[NT];  // fragment (ntile0 + j, k-step 0), lane-linear; padded tiles clamp to the last real one
+    // W fragments (fragment (ntile0 + j, k-step): 1 KiB, lane-linear; padded tiles clamp to the last real one) by buffer loads:
+    // descriptor + per-tile byte offsets in scalar registers (the wave index is made uniform for the compiler), ONE vector
+    // register of address (lane * 16) for all of them (8 address registers less than per-tile pointers).  A second W set
+    // (W double-buffered by k-step, as k_pwc_tiled does) then fits without spills, and was measured: 118.19 vs 118.53 k images/s
+    // without it (200-step A/B, 9 / 6 runs) -- on the float32 interface the X loads and the encoder set the stage time.
+    const int wn_u = __builtin_amdgcn_readfirstlane(wn);
+    const int ntile0u = (int)nb * (BN / 16) + wn_u * NT;
+    const uint64_t wbytes = (uint64_t)p.n_tiles * p.KS * 1024;
+    const uint32_t wrecs = (uint32_t)(wbytes > 0xFFFFFFFFull ? 0xFFFFFFFFull : wbytes);
+    const __amdgpu_buffer_rsrc_t rwh = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.whi), 0, wrecs, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rwl = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(PASSES == 3 ? p.wlo : p.whi), 0, wrecs, 0x00020000);
+    uint32_t wsoff[NT];   // scalar
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        const int nt = ntile0 + j < p.n_tiles ? ntile0 + j : p.n_tiles - 1;
-        wbase[j] = p.whi + (size_t)nt * p.KS * 512 + (size_t)lane * 8;
+        const int nt = ntile0u + j < p.n_tiles ? ntile0u + j : p.n_tiles - 1;
+        wsoff[j] = (uint32_t)nt * (uint32_t)p.KS * 1024u;
     }
+    const uint32_t wvoff = (uint32_t)lane * 16u;
     half8 wh[NT], wl[NT];
     auto load_w = [&](int kstep) {
 #ifdef SLFP_ABL_NOW
@@ -440,8 +452,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) <= 4 ? 2 : 4) void k_pw_til
 #endif
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            wh[j] = *reinterpret_cast<const half8*>(wbase[j] + (size_t)kstep * 512);
-            if constexpr (PASSES == 3) wl[j] = *reinterpret_cast<const half8*>(wbase[j] + wplane + (size_t)kstep * 512);
+            typedef uint32_t u32x4w __attribute__((ext_vector_type(4)));
+            const uint32_t so = wsoff[j] + (uint32_t)kstep * 1024u;
+            wh[j] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rwh, wvoff, so, 0));
+            if constexpr (PASSES == 3) wl[j] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rwl, wvoff, so, 0));
         }
     };
     auto mfma_step = [&](int buf, int ks) {
