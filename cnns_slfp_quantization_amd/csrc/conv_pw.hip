@@ -701,16 +701,24 @@ static int launch_stream_ks(PwParams& p, hipStream_t stream) {
     return check_launch("slfp pointwise (stream) kernel");
 }
 
-// W small enough to live in LDS next to nothing else?
+// CAN the LDS-resident stream kernel take this layer (W next to the tables and the staging area)?  Also what the planner asks
+// for channel counts that are even but not multiples of 4 (only that kernel has the 8-byte access path).
 bool pointwise_stream_fits(int64_t k_pad, int64_t n_pad, int passes) {
     const size_t w = (size_t)k_pad * n_pad * 2 * (passes == 3 ? 2 : 1);
-    return k_pad <= 256 && w <= (size_t)switches().pw_stream_max_kb * 1024;
+    return k_pad <= 256 && w <= (size_t)128 * 1024;
 }
-static bool stream_fits(const ConvPlan& plan, int passes) { return pointwise_stream_fits(plan.k_pad, plan.n_pad, passes); }
+// SHOULD it?  Above SLFP_PW_STREAM_MAX_KB (default 30 KiB of W) the tiled kernel is faster on whole steps (codec.hip: Switches).
+static bool stream_fits(const ConvPlan& plan, int passes, const PwParams& p) {
+    if (!pointwise_stream_fits(plan.k_pad, plan.n_pad, passes)) return false;
+    if (p.K % 4 || p.N % 4) return true;   // 8-byte access path: the stream kernel only
+    const size_t w = (size_t)plan.k_pad * plan.n_pad * 2 * (passes == 3 ? 2 : 1);
+    // three-pass mode (two planes, 3 MFMAs per tile): the stream kernel stays ahead up to 100 KiB (99.4 vs 95.6 k images/s)
+    return w <= (size_t)(passes == 3 ? 100 : switches().pw_stream_max_kb) * 1024;
+}
 
 template <int FMT, int PASSES>
 static int launch_pw(PwParams& p, const ConvPlan& plan, hipStream_t stream) {
-    if (stream_fits(plan, PASSES)) {
+    if (stream_fits(plan, PASSES, p)) {
         switch ((p.K + 31) / 32) {  // k-steps that hold real channels (the blob is zero-padded to p.KS)
             case 1: return launch_stream_ks<FMT, PASSES, 1>(p, stream);
             case 2: return launch_stream_ks<FMT, PASSES, 2>(p, stream);
