@@ -227,6 +227,27 @@ def test_dense_layers_on_codes_are_bit_identical_to_the_float32_interface(lib, d
     assert L.slfp_conv2d_codes_supported(ctypes.byref(d), ctypes.byref(io), 0, 1) == 1
 
 
+def test_dense_layer_on_codes_in_the_float32_equivalent_mode(lib, dev):
+    """SLFP_MFMA_F16X3 on a dense layer: the decode pre-pass also writes the residual plane, so codes in / codes out stay
+    bit-identical to the float32 interface in that mode too (the pointwise code kernels exist for the single-pass mode only)."""
+    from cnns_slfp_quantization_amd.layer_specs import ConvSpec
+    gen = torch.Generator(device=dev).manual_seed(909)
+    s = ConvSpec(c_in=64, c_out=128, k=(3, 3), stride=(1, 1), pad=(1, 1), groups=1, bias=False, h=14, w=14, h_out=14, w_out=14, Ka=0.37, Kw=0.021)
+    lay = _Layer(lib, s, 3, 8, dev, gen)
+    lay.d.mfma_passes = lib.MFMA_F16X3
+    L = lib.load()
+    lay.blob = torch.empty(L.slfp_conv2d_wprep_bytes(ctypes.byref(lay.d)), dtype=torch.uint8, device=dev)
+    lib.check(L.slfp_conv2d_prepare_weights(ctypes.byref(lay.d), lay.w.data_ptr(), lay.blob.data_ptr(), None, _stream()))
+    assert L.slfp_conv2d_kernel_name(ctypes.byref(lay.d)).decode() == "dense_mfma_f16x3"
+    x = _synthetic_input(s, 3, dev, gen)
+    y_ref = lay.fwd_f32(lib, x)
+    xc = _encode(lib, x, s.Ka, lib.FMT_ACT8)
+    y = lay.fwd_codes(lib, xc, True)
+    assert torch.equal(y.view(torch.int32), y_ref.view(torch.int32)), float((y - y_ref).abs().max())
+    yc = lay.fwd_codes(lib, xc, True, 0.2345, 8)
+    assert torch.equal(yc, _encode(lib, y_ref, 0.2345, lib.FMT_ACT8))
+
+
 def test_codes_without_relu_carry_the_sign(lib, dev):
     """conv -> BN -> conv without a ReLU in between (ShuffleNetV2 branches): negative values keep their sign bit."""
     specs = _mobilenet_specs()
