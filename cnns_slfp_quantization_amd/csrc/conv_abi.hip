@@ -409,7 +409,7 @@ int slfp_conv2d_fwd_post(const slfp_conv2d_desc* d, const float* x, const void* 
 
 // ---- 1-byte activation codes between layers (include/slfp.h; csrc/slfp_codes.hpp) ----
 static int codes_route(const slfp_conv2d_desc* d, const slfp_conv2d_io* io, bool has_bias, int relu, ConvPlan* p) {
-    // 0: unsupported; 1: depthwise on codes; 2: pointwise on codes; 3: image stem with code output; 4: dense k x k (needs workspace)
+    // 0: unsupported; 1: depthwise on codes; 2: pointwise on codes; 3: image stem with code output; 4: dense k x k (needs workspace); 5: small-K MFMA stem with code output
     if (!d || !io) return 0;
     if (make_plan(d, p) != SLFP_OK) return 0;
     if (d->x_layout != SLFP_LAYOUT_NHWC || d->y_layout != SLFP_LAYOUT_NHWC) return 0;
@@ -428,6 +428,7 @@ static int codes_route(const slfp_conv2d_desc* d, const slfp_conv2d_io* io, bool
     }
     if (io->y_codes && stem_codes_applicable(*d, *p, relu)) return 3;
     if (io->y_codes && dense_codes_applicable(*d, *p, relu, true)) return 4;
+    if (io->y_codes && stem_small_codes_applicable(*d, *p, relu)) return 5;
     return 0;
 }
 
@@ -475,6 +476,7 @@ extern "C" int slfp_conv2d_fwd_codes_ws(const slfp_conv2d_desc* d, const slfp_co
         return launch_dense_mfma_io(*d, p, x, wprep, bias, post, y, workspace, cio, st);
     }
     const CodeIo cio{false, true, io->y_ka, y_fmt};
+    if (route == 5) return launch_stem_small_io(*d, p, reinterpret_cast<const float*>(x), wprep, bias, post, y, cio, st);
     return launch_stem_codes(*d, p, reinterpret_cast<const float*>(x), reinterpret_cast<const float*>(wprep), bias, post, y, cio, st);
 }
 

@@ -17,6 +17,7 @@
 //     (out*Ka)*Kw roundings, bias and the optional fused BN/ReLU post-op in the epilogue.
 // Precision: single-pass fp16 (SLFP<3,4>) / exact (SFP<3,3>); the float32-equivalent mode keeps k_stem.
 #include "slfp_device.hpp"
+#include "slfp_codes.hpp"
 #include "slfp_host.hpp"
 
 namespace slfp {
@@ -40,6 +41,11 @@ struct StemSmallParams {
     float s1, s2, s1x;
     PostOp post;
     uint32_t nblocks;
+    // 1-byte codes out (slfp_codes.hpp; NT == 4, C_out == 64: VGG-16's first layer): the consumer's quantizer in the epilogue
+    uint8_t* yc;
+    int y_sgn, y_fmt;
+    uint32_t enc_off;     // byte offset of the kEncCode table inside the dynamic LDS (behind the halo tile)
+    EncArgs enc_out;
 };
 
 template <int FMT, int NT>
@@ -48,6 +54,7 @@ __global__ __launch_bounds__(kSsThreads) void k_stem_small(const StemSmallParams
     uint32_t* sT = reinterpret_cast<uint32_t*>(smem);
     _Float16* tile = reinterpret_cast<_Float16*>(smem + 64);   // [IH][row_h] + one zero slot at the end
     lut_fill<FMT>(sT);
+    if (p.yc) enc_fill<kSsThreads>(reinterpret_cast<uint2*>(smem + p.enc_off), p.enc_out);   // published by the barrier below
 
     uint32_t b = xcd_remap(blockIdx.x, p.nblocks);
     const int tw = b % p.tiles_w; b /= p.tiles_w;
@@ -132,6 +139,32 @@ __global__ __launch_bounds__(kSsThreads) void k_stem_small(const StemSmallParams
 #pragma unroll
         for (int j = 0; j < NT; ++j)
             acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        if constexpr (NT == 4) {
+            if (p.yc) {   // (wave-uniform) encode the 4 channel tiles, regroup to 16 consecutive channels per lane, one 16-byte store
+                const unsigned char* senc = smem + p.enc_off;
+                PostOp po = p.post;
+                po.relu = 0;   // folded into the quantizer
+                uint32_t c[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 bq = bqv[j];
+                    float4 r;
+                    r.x = ((acc[j][0] + bq.x) * p.s1x) * p.s2;
+                    r.y = ((acc[j][1] + bq.y) * p.s1x) * p.s2;
+                    r.z = ((acc[j][2] + bq.z) * p.s1x) * p.s2;
+                    r.w = ((acc[j][3] + bq.w) * p.s1x) * p.s2;
+                    r = post_apply_v(r, po, pvv[j]);
+                    if (p.y_sgn) c[j] = code_sign4(enc4_code<false>(r, p.enc_out.r1, p.enc_out.lo, p.enc_out.hi, senc), r, p.y_fmt);
+                    else c[j] = enc4_code_relu(r, p.enc_out.r1, p.enc_out.lo, p.enc_out.hi, senc);
+                }
+                rows_transpose4(c[0], c[1], c[2], c[3]);
+                if (goh < p.Ho && gow < p.Wo && kq * 16 < p.O) {
+                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                    *reinterpret_cast<u32x4*>(p.yc + (((size_t)n * p.Ho + goh) * p.Wo + gow) * p.O + kq * 16) = u32x4{c[0], c[1], c[2], c[3]};
+                }
+                continue;
+            }
+        }
         if (goh < p.Ho && gow < p.Wo) {
             float* yp = p.y + (((size_t)n * p.Ho + goh) * p.Wo + gow) * p.O;
 #pragma unroll
@@ -176,10 +209,23 @@ static int launch_stem_small_f(const StemSmallParams& p, int nt, size_t lds, hip
     return check_launch("slfp small-K MFMA stem kernel");
 }
 
+// code output: the 64-channel form only (four channel tiles regroup to 16 consecutive codes per lane)
+bool stem_small_codes_applicable(const slfp_conv2d_desc& d, const ConvPlan& plan, int post_flags) {
+    return plan.family == kStemSmall && !plan.repad && d.c_out == 64 && !(post_flags & SLFP_POST_LAYEROUT);
+}
+
 int launch_stem_small(const slfp_conv2d_desc& d, const ConvPlan& plan, const float* x, const void* wblob,
                       const float* bias, const PostOp& post, float* y, hipStream_t stream) {
+    const CodeIo io{false, false, 1.f, kFmtAct8};
+    return launch_stem_small_io(d, plan, x, wblob, bias, post, y, io, stream);
+}
+
+int launch_stem_small_io(const slfp_conv2d_desc& d, const ConvPlan& plan, const float* x, const void* wblob,
+                         const float* bias, const PostOp& post, void* y_any, const CodeIo& io, hipStream_t stream) {
+    float* y = reinterpret_cast<float*>(y_any);
     StemSmallParams p;
     p.x = x; p.w = reinterpret_cast<const _Float16*>(wblob); p.bias = bias; p.y = y; p.post = post;
+    p.yc = nullptr; p.y_sgn = 0; p.y_fmt = kFmtAct8; p.enc_off = 0; p.enc_out.valid = 0;
     p.N = (int)d.n; p.H = (int)d.h; p.W = (int)d.w; p.C = (int)d.c_in; p.O = (int)d.c_out;
     p.KH = (int)d.kh; p.KW = (int)d.kw; p.S = d.stride_h; p.ph = d.pad_h; p.pw = d.pad_w;
     p.Ho = (int)plan.h_out; p.Wo = (int)plan.w_out;
@@ -193,9 +239,20 @@ int launch_stem_small(const slfp_conv2d_desc& d, const ConvPlan& plan, const flo
     const int64_t nblocks = (int64_t)p.N * p.tiles_h * p.tiles_w;
     if (nblocks > 0x7FFFFFFF) return fail(SLFP_ERR_UNSUPPORTED, "small stem: grid too large");
     p.nblocks = (uint32_t)nblocks;
-    const size_t lds = 64 + ((size_t)p.IH * p.row_h + 8) * sizeof(_Float16);
-    if (lds > 64 * 1024) return fail(SLFP_ERR_UNSUPPORTED, "small stem: halo tile needs %zu B of LDS", lds);
+    size_t lds = 64 + ((size_t)p.IH * p.row_h + 8) * sizeof(_Float16);
     const int nt = stem_small_tiles(d);
+    if (io.y_codes) {
+        const EncArgs* t = enc_table(io.y_ka, io.y_fmt, kEncCode);
+        if (!t->valid || nt != 4 || d.c_out != 64) return fail(SLFP_ERR_UNSUPPORTED, "small stem: no code output for this layer");
+        p.enc_out = *t;
+        p.yc = reinterpret_cast<uint8_t*>(y_any);
+        p.y = nullptr;
+        p.y_sgn = post.relu ? 0 : 1;
+        p.y_fmt = io.y_fmt;
+        p.enc_off = (uint32_t)((lds + 15) & ~(size_t)15);
+        lds = p.enc_off + (size_t)kEncEntries * 8;
+    }
+    if (lds > 64 * 1024) return fail(SLFP_ERR_UNSUPPORTED, "small stem: halo tile needs %zu B of LDS", lds);
     return plan.fmt_act == kFmtAct8 ? launch_stem_small_f<kFmtAct8>(p, nt, lds, stream)
                                     : launch_stem_small_f<kFmtSfp7>(p, nt, lds, stream);
 }

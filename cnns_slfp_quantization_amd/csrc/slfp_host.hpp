@@ -164,6 +164,9 @@ bool stem_small_applicable(const slfp_conv2d_desc& d, int passes);
 int stem_small_tiles(const slfp_conv2d_desc& d);
 int launch_stem_small(const slfp_conv2d_desc& d, const ConvPlan& p, const float* x, const void* wblob,
                       const float* bias, const PostOp& post, float* y, hipStream_t stream);
+bool stem_small_codes_applicable(const slfp_conv2d_desc& d, const ConvPlan& p, int post_flags);   // float32 in -> codes out (C_out == 64)
+int launch_stem_small_io(const slfp_conv2d_desc& d, const ConvPlan& p, const float* x, const void* wblob, const float* bias,
+                         const PostOp& post, void* y_any, const CodeIo& io, hipStream_t stream);
 
 // XCD-aware block remap (MI355X: 8 XCDs, blocks are dealt round-robin over them, so
 // blocks b and b+8 share an L2).  Maps the hardware block id to a logical id such that

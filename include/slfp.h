@@ -173,7 +173,8 @@ int slfp_dwpw_fwd(const slfp_conv2d_desc* dw, const slfp_conv2d_desc* pw, const 
  * slfp_encode_f32).  Both tensors are NHWC; x, y and wprep 16-byte aligned; wprep is the blob of
  * slfp_conv2d_prepare_weights for the same descriptor.  Supported: 3x3 depthwise (x_codes), 1x1 (x_codes; C_in a
  * multiple of 32, C_out of 16 with y_codes), and the 3x3 stride-2 RGB stem -> 32 channels (float32 in, y_codes):
- * every layer of nets_imgnet/mobilenetv1.py:43-57; dense k x k layers through slfp_conv2d_fwd_codes_ws (below).
+ * every layer of nets_imgnet/mobilenetv1.py:43-57; the 3x3 RGB stem -> 64 channels of VGG-16 (float32 in, y_codes); dense k x k
+ * layers through slfp_conv2d_fwd_codes_ws (below).
  * slfp_conv2d_codes_supported answers 1 / 0 without device work. */
 typedef struct slfp_conv2d_io {
     int32_t x_codes;  /* 0: x is float32 (as slfp_conv2d_fwd); 1: x is uint8 codes of QA(. / d->ka), format of d->qbits */

@@ -227,6 +227,30 @@ def test_dense_layers_on_codes_are_bit_identical_to_the_float32_interface(lib, d
     assert L.slfp_conv2d_codes_supported(ctypes.byref(d), ctypes.byref(io), 0, 1) == 1
 
 
+@pytest.mark.parametrize("qbits", [8, 7])
+def test_small_k_stem_writes_the_next_layers_codes(lib, dev, qbits):
+    """VGG-16's first layer (3x3 s1 3 -> 64 on the one-k-step MFMA stem, nets_cifar/vgg16.py:31): float32 image in, the
+    consumer's codes out == slfp_encode_f32(float32 output of the fused layer, Ka_next); with and without a ReLU; ragged size."""
+    from cnns_slfp_quantization_amd.layer_specs import ConvSpec
+    gen = torch.Generator(device=dev).manual_seed(31 + qbits)
+    fmt = lib.FMT_ACT8 if qbits == 8 else lib.FMT_SFP7
+    L = lib.load()
+    for h, st in ((37, 1), (32, 2)):
+        ho = (h + 2 - 3) // st + 1
+        s = ConvSpec(c_in=3, c_out=64, k=(3, 3), stride=(st, st), pad=(1, 1), groups=1, bias=False, h=h, w=h, h_out=ho, w_out=ho, Ka=0.17, Kw=0.05)
+        for relu in (True, False):
+            lay = _Layer(lib, s, 3, qbits, dev, gen, post=True, relu=relu)
+            assert lay.kernel.startswith("stem_small_mfma"), lay.kernel
+            x = _synthetic_input(s, 3, dev, gen, signed=True)
+            y_ref = lay.fwd_f32(lib, x)
+            yc = lay.fwd_codes(lib, x, False, 0.31, qbits)
+            bad = int((yc != _encode(lib, y_ref, 0.31, fmt)).sum())
+            assert bad == 0, (h, st, relu, bad, yc.numel())
+    s = ConvSpec(c_in=3, c_out=24, k=(3, 3), stride=(1, 1), pad=(1, 1), groups=1, bias=False, h=16, w=16, h_out=16, w_out=16, Ka=0.17, Kw=0.05)
+    io = lib.ConvIo(x_codes=0, y_codes=1, y_ka=0.31, y_qbits=qbits)
+    assert L.slfp_conv2d_codes_supported(ctypes.byref(_desc(lib, s, 2, qbits)), ctypes.byref(io), 0, 1) == 0   # ShuffleNetV2's 24-channel stem: no
+
+
 def test_dense_layer_on_codes_in_the_float32_equivalent_mode(lib, dev):
     """SLFP_MFMA_F16X3 on a dense layer: the decode pre-pass also writes the residual plane, so codes in / codes out stay
     bit-identical to the float32 interface in that mode too (the pointwise code kernels exist for the single-pass mode only)."""

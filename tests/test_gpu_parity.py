@@ -1254,7 +1254,7 @@ def test_vgg16_code_links_run_on_the_dense_kernels_and_are_bit_identical(dev):
         assert fusion.fuse_bn_relu(m) == 13
         y_fused = m(x)
         n = fusion.link_codes(m, x)
-        assert n >= 7, n   # 1 + 2 + 2 + 2 inside stages 2-5 (+ stage 1 if the 3-channel stem can hand over codes)
+        assert n == 8, n   # 1 + 1 + 2 + 2 + 2 inside the five stages (the 3 -> 64 stem hands over codes too)
         y_codes = m(x)
         kernels = [c._last_kernel for c in convs]
     assert sum("codes_in" in k for k in kernels) == n and sum("codes_out" in k for k in kernels) == n, kernels
