@@ -478,12 +478,15 @@ def run_codes_config(L, net, batch, qbits, steps, warmup, dev):
 
     def direct(i):
         """Does layer i's (fused BN + ReLU) output feed layer i+1 directly, as fusion.link_codes requires?  MobileNetV1: always
-        (nets_imgnet/mobilenetv1.py:43-57); VGG-16: inside a stage (a MaxPool2d halves the size between stages,
-        nets_cifar/vgg16.py:30-92; it keeps float32)."""
+        (nets_imgnet/mobilenetv1.py:43-57); VGG-16: inside a stage, and from one stage to the next through its MaxPool2d, which
+        pools the codes (slfp_maxpool2d_codes; nets_cifar/vgg16.py:30-92) -- the pool itself is outside the conv path on either
+        interface."""
         if i < 0 or i + 1 >= len(specs):
             return False
         a, b = specs[i], specs[i + 1]
-        return a.c_out == b.c_in and a.h_out == b.h and a.w_out == b.w
+        same = a.h_out == b.h and a.w_out == b.w
+        pooled = net.startswith("vgg16") and a.h_out == 2 * b.h and a.w_out == 2 * b.w
+        return a.c_out == b.c_in and (same or pooled)
 
     # a hand-over becomes codes where both kernels exist: decided left to right, as link_codes does
     x_codes = [False] * len(specs)

@@ -24,7 +24,7 @@ SYMBOLS = (
     "slfp_linear_workspace_bytes", "slfp_linear_fwd", "slfp_linear_prepare_weights", "slfp_linear_fwd_prepared",
     "slfp_nchw_to_nhwc_f32", "slfp_nhwc_to_nchw_f32", "slfp_debug_div_mismatches",
     "slfp_debug_enc_mismatches", "slfp_enc_table_ok", "slfp_dwpw_supported", "slfp_dwpw_fwd",
-    "slfp_conv2d_codes_supported", "slfp_conv2d_fwd_codes", "slfp_conv2d_fwd_codes_ws", "slfp_debug_code_mismatches", "slfp_debug_reload_switches",
+    "slfp_conv2d_codes_supported", "slfp_conv2d_fwd_codes", "slfp_conv2d_fwd_codes_ws", "slfp_maxpool2d_codes", "slfp_debug_code_mismatches", "slfp_debug_reload_switches",
     "slfp_debug_enc_hl_mismatches",
 )
 
@@ -104,6 +104,7 @@ def load():
         "slfp_conv2d_codes_supported": (ci, [dp, ctypes.POINTER(ConvIo), ci, ci]),
         "slfp_conv2d_fwd_codes": (ci, [dp, ctypes.POINTER(ConvIo), vp, vp, vp, vp, vp, ci, vp, vp]),
         "slfp_conv2d_fwd_codes_ws": (ci, [dp, ctypes.POINTER(ConvIo), vp, vp, vp, vp, vp, ci, vp, vp, vp]),
+        "slfp_maxpool2d_codes": (ci, [vp, vp, i64, i64, i64, i64, ci, ci, ci, ci, ci, ci, ci, vp]),
         "slfp_debug_code_mismatches": (ci, [cf, ci, vp, vp]),
         "slfp_debug_reload_switches": (None, []),
         "slfp_debug_enc_hl_mismatches": (ci, [cf, ci, vp, vp]),

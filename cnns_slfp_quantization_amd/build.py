@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libslfp_hip.so")
-SOURCES = ["codec.hip", "enc_table.hip", "conv_dw.hip", "conv_dw2.hip", "conv_dwpw.hip", "conv_dwc.hip", "conv_pw.hip", "conv_pw_codes.hip", "conv_direct.hip", "conv_dense.hip", "conv_stem_mfma.hip", "conv_stem_small.hip", "conv_abi.hip"]
+SOURCES = ["codec.hip", "enc_table.hip", "conv_dw.hip", "conv_dw2.hip", "conv_dwpw.hip", "conv_dwc.hip", "conv_pw.hip", "conv_pw_codes.hip", "conv_direct.hip", "conv_dense.hip", "conv_stem_mfma.hip", "conv_stem_small.hip", "pool_codes.hip", "conv_abi.hip"]
 # No fast-math: the SLFP encode needs IEEE float32 division and un-contracted rescales.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-ffp-contract=off",
          "-Wall", "-Wno-unused-variable", "-Wno-unused-but-set-variable"]

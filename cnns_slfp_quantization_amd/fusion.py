@@ -310,6 +310,29 @@ def unfuse_dw_pw(model):
 
 
 # ------------------------------------------------------------------ 1-byte activation codes between layers
+class CodeMaxPool2d(nn.Module):
+    """An nn.MaxPool2d inside a code chain (link_codes): uint8 codes are pooled as codes (slfp_maxpool2d_codes: the class of a
+    window's largest input -- bit-identical to pooling the float32 tensor and encoding it), anything else goes to the original
+    module, which this wrapper keeps (`pool`; it has no parameters, the state dict does not change)."""
+
+    def __init__(self, pool, q_bit):
+        super().__init__()
+        self.pool = pool
+        self.q_bit = int(q_bit)
+
+    def forward(self, x):
+        if x.dtype == torch.uint8:
+            from .sfp_quant import hip_maxpool_codes
+            p = self.pool
+            return hip_maxpool_codes(x, p.kernel_size, p.stride, p.padding, self.q_bit)
+        return self.pool(x)
+
+
+def _poolable(m):
+    return (isinstance(m, nn.MaxPool2d) and not m.ceil_mode and not m.return_indices
+            and (m.dilation == 1 or m.dilation == (1, 1)))
+
+
 def link_codes(model, example_input=None):
     """After fuse_bn_relu: wherever a Conv2d_Q's (fused BN + ReLU) output feeds the next Conv2d_Q of an nn.Sequential
     directly (only nn.Identity in between -- nets_imgnet/mobilenetv1.py:24-33 after fusion), link the two: the producer's
@@ -367,7 +390,15 @@ def link_codes(model, example_input=None):
     nested = {c for m in model.modules() if isinstance(m, nn.Sequential) for c in m._modules.values() if isinstance(c, nn.Sequential)}
     n_links = 0
     for seq in [m for m in model.modules() if isinstance(m, nn.Sequential) and m not in nested]:
-        mods = [m for m in flat(seq) if not isinstance(m, nn.Identity)]
+        allm = [m for m in flat(seq) if not isinstance(m, nn.Identity)]
+        # nn.MaxPool2d modules between two convs stay inside the chain (CodeMaxPool2d): drop them from the adjacency list and
+        # remember which ones sit behind each conv
+        mods, pools_after = [], {}
+        for m in allm:
+            if _poolable(m) and mods and eligible(mods[-1]):
+                pools_after.setdefault(len(mods) - 1, []).append(m)
+            else:
+                mods.append(m)
         # candidate links: consecutive eligible convs
         cand = [i for i in range(len(mods) - 1) if eligible(mods[i]) and eligible(mods[i + 1])]
         # a conv can consume codes only if its producer link exists; walk left to right and keep links whose two sides have kernels
@@ -385,9 +416,16 @@ def link_codes(model, example_input=None):
             # checked when its own link is made; if that fails b keeps float32 out)
             if not supported(b, True, None):
                 continue
+            if pools_after.get(i) and a.out_channels % 4:
+                continue   # slfp_maxpool2d_codes needs C % 4 == 0
             a._code_out = out
             linked_in.add(i + 1)
             n_links += 1
+            for pm in pools_after.get(i, []):   # the pools between a and b now see codes
+                for parent in [m for m in model.modules() if not isinstance(m, CodeMaxPool2d)]:
+                    for name, child in list(parent._modules.items()):
+                        if child is pm:
+                            parent._modules[name] = CodeMaxPool2d(pm, b.q_bit)
     return n_links
 
 
@@ -404,7 +442,7 @@ def link_codes_traced(model, example_input):
     import ctypes as _ct
     from . import _lib
     from .conv2d_func import _f32, _scalar_scale, options
-    conv_io, relu_io, order, keep = {}, [], [], []
+    conv_io, relu_io, pool_io, order, keep = {}, [], [], [], []
     hooks = []
     for m in model.modules():
         if _is_conv_q(m):
@@ -418,6 +456,11 @@ def link_codes_traced(model, example_input):
                 relu_io.append((inp[0], out))
                 keep.append((inp[0], out))
             hooks.append(m.register_forward_hook(_rec_relu))
+        elif _poolable(m):
+            def _rec_pool(mod, inp, out):
+                pool_io.append((inp[0], out, mod))
+                keep.append((inp[0], out))
+            hooks.append(m.register_forward_hook(_rec_pool))
     try:
         with torch.no_grad():
             y0 = model(example_input)
@@ -428,9 +471,13 @@ def link_codes_traced(model, example_input):
         return 0   # a module that runs twice per forward has no single producer / consumer
     producer = {id(out): c for c, (_, out) in conv_io.items()}
     relu_src = {id(out): inp for inp, out in relu_io}
+    pool_src = {id(out): (inp, mod) for inp, out, mod in pool_io}
+    pool_uses = {}
+    for _, _, mod in pool_io:
+        pool_uses[mod] = pool_uses.get(mod, 0) + 1
 
-    def eligible(m):
-        return (m.q_bit in (8, 7) and not m.training and isinstance(m.padding, tuple) and m._code_out is None
+    def eligible(m, producer_side=False):
+        return (m.q_bit in (8, 7) and not m.training and isinstance(m.padding, tuple) and (m._code_out is None or not producer_side)
                 and (m.bias is None or getattr(m, "_scaled_bias", False)) and not (m._post is not None and (int(m._post[2]) & 2)))
 
     def supported(m, x_codes, out, flags):
@@ -449,28 +496,45 @@ def link_codes_traced(model, example_input):
 
     cand = {}
     for b in order:
-        t, via_relu = conv_io[b][0], False
-        if id(t) in relu_src:
-            t, via_relu = relu_src[id(t)], True
+        t, via_relu, pools = conv_io[b][0], False, []
+        for _ in range(4):   # look back through nn.ReLU / nn.MaxPool2d modules (a ReLU'd tensor pools the same either way)
+            if id(t) in relu_src:
+                t, via_relu = relu_src[id(t)], True
+            elif id(t) in pool_src and pool_uses[pool_src[id(t)][1]] == 1:
+                t, pm = pool_src[id(t)]
+                pools.append(pm)
+            else:
+                break
         a = producer.get(id(t))
-        if a is None or a is b or not eligible(a) or not eligible(b):
+        if a is None or a is b or not eligible(a, producer_side=True) or not eligible(b):
             continue
-        cand.setdefault(a, []).append((b, via_relu))
-    made, reads_codes = [], set()
+        if conv_io[b][0].dtype == torch.uint8:
+            continue   # already linked
+        if pools and a.out_channels % 4:
+            continue   # slfp_maxpool2d_codes needs C % 4 == 0
+        cand.setdefault(a, []).append((b, via_relu, pools))
+    made, reads_codes, wrapped = [], set(), []
     for a in order:   # execution order: whether `a` itself reads codes is known when its own link is decided
         if a not in cand or len(cand[a]) != 1:
             continue
-        b, via_relu = cand[a][0]
+        b, via_relu, pools = cand[a][0]
         flags = (int(a._post[2]) if a._post is not None else 0) | (1 if via_relu else 0)
         out = (float(_scalar_scale(b.Ka, "Ka")), int(b.q_bit))
         bflags = int(b._post[2]) if b._post is not None else 0
-        if not supported(a, a in reads_codes, out, flags) or not supported(b, True, None, bflags):
+        a_in = a in reads_codes or conv_io[a][0].dtype == torch.uint8   # does `a` itself read codes (an earlier link)?
+        if not supported(a, a_in, out, flags) or not supported(b, True, b._code_out, bflags):
             continue
         made.append((a, a._post))
         a._post = ((a._post[0], a._post[1]) if a._post is not None else (None, None)) + (flags,)
         a._code_out = out
         a._pre_link_post = made[-1][1]
         reads_codes.add(b)
+        for pm in pools:   # the pools between a and b now see codes
+            for parent in [m for m in model.modules() if not isinstance(m, CodeMaxPool2d)]:
+                for name, child in list(parent._modules.items()):
+                    if child is pm:
+                        parent._modules[name] = CodeMaxPool2d(pm, b.q_bit)
+                        wrapped.append((parent, name, pm))
     if not made:
         return 0
     ok = False
@@ -484,6 +548,8 @@ def link_codes_traced(model, example_input):
         for a, post in made:
             a._post, a._code_out = post, None
             del a._pre_link_post
+        for parent, name, pm in wrapped:
+            parent._modules[name] = pm
         return 0
     return len(made)
 
@@ -491,6 +557,10 @@ def link_codes_traced(model, example_input):
 def unlink_codes(model):
     """Undo link_codes / link_codes_traced."""
     n = 0
+    for parent in model.modules():
+        for name, child in list(parent._modules.items()):
+            if isinstance(child, CodeMaxPool2d):
+                parent._modules[name] = child.pool
     for m in model.modules():
         if _is_conv_q(m) and m._code_out is not None:
             m._code_out = None

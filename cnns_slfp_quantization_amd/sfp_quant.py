@@ -82,7 +82,28 @@ def hip_decode(codes, fmt):
     return y
 
 
+def hip_maxpool_codes(codes, kernel_size, stride, padding, q_bit):
+    """nn.MaxPool2d (floor mode, dilation 1) on a channels_last tensor of extended activation codes (slfp_maxpool2d_codes):
+    equal to encoding the pooled float32 tensor, bit for bit."""
+    if not codes.is_cuda or codes.dtype != torch.uint8 or codes.dim() != 4:
+        raise TypeError("slfp maxpool: expected a 4-d ROCm ('cuda') uint8 tensor of codes")
+    if not codes.is_contiguous(memory_format=torch.channels_last):
+        codes = codes.contiguous(memory_format=torch.channels_last)
+    kh, kw = (kernel_size, kernel_size) if isinstance(kernel_size, int) else kernel_size
+    stride = kernel_size if stride is None else stride
+    sh, sw = (stride, stride) if isinstance(stride, int) else stride
+    ph, pw = (padding, padding) if isinstance(padding, int) else padding
+    n, c, h, w = codes.shape
+    ho, wo = (h + 2 * ph - kh) // sh + 1, (w + 2 * pw - kw) // sw + 1
+    y = torch.empty((n, c, ho, wo), dtype=torch.uint8, device=codes.device, memory_format=torch.channels_last)
+    L = _lib.load()
+    with torch.cuda.device(codes.device):
+        _lib.check(L.slfp_maxpool2d_codes(codes.data_ptr(), y.data_ptr(), n, h, w, c, kh, kw, sh, sw, ph, pw, int(q_bit), _stream_handle(codes)))
+    return y
+
+
 def _make_qfn(fmt):
+
     class qfn(torch.autograd.Function):
         @staticmethod
         def forward(ctx, input):

@@ -194,6 +194,13 @@ int slfp_conv2d_fwd_codes(const slfp_conv2d_desc* d, const slfp_conv2d_io* io, c
 int slfp_conv2d_fwd_codes_ws(const slfp_conv2d_desc* d, const slfp_conv2d_io* io, const void* x, const void* wprep,
                              const float* bias, const float* post_scale, const float* post_shift, int relu, void* y,
                              void* workspace, void* stream);
+/* nn.MaxPool2d (floor mode, dilation 1) on a tensor of activation codes (NHWC, C a multiple of 4; 16-byte aligned): the class
+ * of a window's largest input is the highest class among its codes in the order of the classes' pre-images (the clamp literal
+ * of Qbits 8 ranks above the top regular code, "tiny" above exact zero, signed codes by decreasing magnitude), so
+ * y == slfp_encode_f32(max_pool2d(t), ka, fmt | SLFP_FMT_EXT) wherever x == slfp_encode_f32(t, ka, fmt | SLFP_FMT_EXT), bit for
+ * bit -- the pools between VGG-16's stages (nets_cifar/vgg16.py:39,49,63,78,92) can stay inside a code chain. */
+int slfp_maxpool2d_codes(const uint8_t* x, uint8_t* y, int64_t n, int64_t h, int64_t w, int64_t c, int kh, int kw, int sh, int sw,
+                         int ph, int pw, int qbits, void* stream);
 /* Self-check of the producer side: sweeps ALL 2^32 float32 inputs on the device; out3[0] = inputs whose table-driven code
  * (signed variant) differs from slfp_encode_f32(.., fmt | SLFP_FMT_EXT), out3[1] = the same for the unsigned variant a
  * producer with a ReLU epilogue runs (inputs >= +0 and -0), out3[2] = code bytes whose decode-table entries (float32 and

@@ -251,6 +251,40 @@ def test_small_k_stem_writes_the_next_layers_codes(lib, dev, qbits):
     assert L.slfp_conv2d_codes_supported(ctypes.byref(_desc(lib, s, 2, qbits)), ctypes.byref(io), 0, 1) == 0   # ShuffleNetV2's 24-channel stem: no
 
 
+@pytest.mark.parametrize("qbits", [8, 7])
+def test_maxpool_on_codes_equals_encoding_the_pooled_tensor(lib, dev, qbits):
+    """slfp_maxpool2d_codes: pooling the codes == slfp_encode_f32(max_pool2d(float32 tensor)) bit for bit -- post-ReLU and
+    signed tensors with every special class in them (exact zeros, the 1e-10 class, values beyond the clamp, whose Qbits-8
+    literal is 3 ulp BELOW the top regular value), VGG-16's 2x2 / 2 pools, ResNet-50's 3x3 / 2 pad 1, 16- and 4-channel lanes."""
+    import torch.nn.functional as F
+    from cnns_slfp_quantization_amd.sfp_quant import hip_maxpool_codes
+    fmt = lib.FMT_ACT8 if qbits == 8 else lib.FMT_SFP7
+    gen = torch.Generator(device=dev).manual_seed(11 + qbits)
+    ka = 0.23
+    for (n, c, h, w), (k, st, pd), signed in (((3, 64, 30, 30), (2, 2, 0), False), ((2, 12, 17, 19), (2, 2, 0), True),
+                                               ((2, 32, 23, 23), (3, 2, 1), False), ((2, 16, 9, 9), (3, 1, 1), True)):
+        x = torch.randn((n, c, h, w), generator=gen, device=dev) * (5.0 * ka)
+        x = x if signed else torch.relu(x)
+        x.view(-1)[::7] = 15.4 * ka            # the top regular class
+        x.view(-1)[3::11] = 40.0 * ka          # beyond the clamp
+        x.view(-1)[5::13] = 0.03 * ka          # the 1e-10 class
+        x.view(-1)[6::17] = 0.0
+        if signed:
+            x.view(-1)[8::19] = -40.0 * ka
+        x = x.contiguous(memory_format=torch.channels_last)
+        def enc(t):   # elementwise in memory order, keeping the channels_last strides
+            t = t.contiguous(memory_format=torch.channels_last)
+            c = torch.empty_like(t, dtype=torch.uint8)
+            lib.check(lib.load().slfp_encode_f32(t.data_ptr(), c.data_ptr(), t.numel(), float(np.float32(ka)), fmt | lib.FMT_EXT, _stream()))
+            return c
+        want = enc(F.max_pool2d(x, k, st, pd))
+        got = hip_maxpool_codes(enc(x), k, st, pd, qbits)
+        assert got.shape == want.shape and torch.equal(got, want), ((n, c, h, w), (k, st, pd), signed, int((got != want).sum()))
+    L = lib.load()
+    z = torch.zeros((1, 6, 4, 4), dtype=torch.uint8, device=dev).contiguous(memory_format=torch.channels_last)
+    assert L.slfp_maxpool2d_codes(z.data_ptr(), z.data_ptr(), 1, 4, 4, 6, 2, 2, 2, 2, 0, 0, qbits, _stream()) == lib.ERR_UNSUPPORTED
+
+
 def test_dense_layer_on_codes_in_the_float32_equivalent_mode(lib, dev):
     """SLFP_MFMA_F16X3 on a dense layer: the decode pre-pass also writes the residual plane, so codes in / codes out stay
     bit-identical to the float32 interface in that mode too (the pointwise code kernels exist for the single-pass mode only)."""

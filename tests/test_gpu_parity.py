@@ -1245,7 +1245,7 @@ def _build_r3(net, dev, qbits=None, channels_last=True):
 def test_vgg16_code_links_run_on_the_dense_kernels_and_are_bit_identical(dev):
     """nets_cifar/vgg16.py:30-92 (the fixture's net) after fuse_bn_relu + link_codes: inside every nn.Sequential stage the
     hand-overs conv -> conv become 1-byte codes on the dense 3x3 kernels (slfp_conv2d_fwd_codes_ws: decode pre-pass / code
-    epilogue; the MaxPool2d at the end of a stage keeps float32); the logits do not change by a single bit."""
+    epilogue), the MaxPool2d between two stages pools the codes (slfp_maxpool2d_codes); the logits do not change by a single bit."""
     from cnns_slfp_quantization_amd import fusion
     import utils.conv2d_func as cf
     m, x, gold, tap = _build_r3("vgg16", dev)
@@ -1254,13 +1254,18 @@ def test_vgg16_code_links_run_on_the_dense_kernels_and_are_bit_identical(dev):
         assert fusion.fuse_bn_relu(m) == 13
         y_fused = m(x)
         n = fusion.link_codes(m, x)
-        assert n == 8, n   # 1 + 1 + 2 + 2 + 2 inside the five stages (the 3 -> 64 stem hands over codes too)
+        assert n == 8, n   # 1 + 1 + 2 + 2 + 2 inside the five nn.Sequential stages (the 3 -> 64 stem hands over codes too)
+        n += fusion.link_codes_traced(m, x)   # + the 4 hand-overs from one stage to the next, through its MaxPool2d (pooled as codes)
+        assert n == 12, n
         y_codes = m(x)
         kernels = [c._last_kernel for c in convs]
     assert sum("codes_in" in k for k in kernels) == n and sum("codes_out" in k for k in kernels) == n, kernels
     assert any(k.startswith("dense_mfma") and "codes_in" in k and "codes_out" in k for k in kernels), kernels
     assert torch.equal(y_codes.view(torch.int32), y_fused.view(torch.int32)), float((y_codes - y_fused).abs().max())
-    assert fusion.unlink_codes(m) == n
+    assert sum(isinstance(c, fusion.CodeMaxPool2d) for c in m.modules()) == 4
+    assert fusion.unlink_codes(m) == n and not any(isinstance(c, fusion.CodeMaxPool2d) for c in m.modules())
+    with torch.no_grad():
+        assert torch.equal(m(x), y_fused)
 
 
 def test_resnet50_traced_code_links_are_verified_and_bit_identical(dev):
