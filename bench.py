@@ -422,6 +422,24 @@ def run_config(L, net, batch, qbits, passes, steps, warmup, dev, rank, world, po
         for l in layers:
             l.set_passes(L, stream, passes)
 
+    # the north-star scope by itself (BASELINE.json: "3x3 depthwise + 1x1 pointwise"): the same steps WITHOUT the image stem, by
+    # the wall clock -- the per-family HIP-event sums above carry ~2 us of event overhead per launch that a step does not have
+    scope = None
+    if exact_too and world == 1:
+        sub = [l for l in layers if l.spec.c_in > 4]
+        if len(sub) != len(layers) and sub:
+            def sub_step():
+                for l in sub:
+                    l.run(L, stream)
+            for _ in range(max(1, warmup // 4)):
+                sub_step()
+            dts = timed_steps(sub_step, steps, 1, dev)
+            sub_bytes = sum(l.bytes for l in sub)
+            scope = {"layers": len(sub), "ms_per_step": round(dts / steps * 1e3, 4),
+                     "achieved_GB/s": round(sub_bytes * steps / dts / 1e9, 1),
+                     "hbm_roofline_frac": round(sub_bytes * steps / dts / 1e9 / HBM_PEAK_GBS, 4),
+                     "note": "depthwise + pointwise layers only (no stem), wall clock over the same number of steps"}
+
     imgs = batch * world * steps
     value = imgs / dt
     bytes_img = layer_specs.algorithmic_bytes_per_image(net, batch)
@@ -455,6 +473,8 @@ def run_config(L, net, batch, qbits, passes, steps, warmup, dev, rank, world, po
                            "algorithmic_flops_per_launch": int(dom["flops"] / dom["launches"])}
     if exact_value is not None:
         res["value_pointwise_f16x3_float32_equivalent"] = round(exact_value, 1)
+    if scope is not None:
+        res["dw_pw_scope"] = scope
     if per_layer and rank == 0:
         for l, ms in zip(layers, layer_ms):
             sp = l.spec
@@ -686,6 +706,8 @@ def main():
         }
         if "value_pointwise_f16x3_float32_equivalent" in res:
             out["value_pointwise_f16x3_float32_equivalent"] = res["value_pointwise_f16x3_float32_equivalent"]
+        if "dw_pw_scope" in res:
+            out["dw_pw_scope"] = res["dw_pw_scope"]
     if world == 1 and rank == 0:
         if not args.no_other_configs:
             # BASELINE configs 3-5 at their named batch sizes: short runs (3 steps), each with its own roofline object
