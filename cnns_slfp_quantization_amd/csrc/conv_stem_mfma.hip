@@ -167,6 +167,146 @@ __global__ __launch_bounds__(kSmThreads, 2) void k_stem_mfma(const StemMfmaParam
     }
 }
 
+// ======================================================================================
+// k_stem_rows (round 3): the same contraction WITHOUT the im2row workspace.  A workgroup owns an 8 x 32 tile of output
+// pixels; the input rows it needs ((8-1)*S + KH rows x ((32-1)*S + KW)*C elements) are loaded once, encoded to fp16 and kept
+// in LDS as plain rows (the encoded image never touches HBM: the im2row copy was 400 MB written + re-read per step on
+// SqueezeNet's 7x7 s2 stem at batch 256, next to a 154 MB input and a 1.17 GB output).  With C_in = 3 a tap row's KW*C inputs
+// are contiguous in such a row, so lane (pixel, kq) of k-step (kh, sub) reads elements sub*32 + kq*8 .. +7 behind its
+// pixel's window origin -- 4-byte aligned when S*C is even: four ds_read_b32.  Elements past the run (r >= KW*C) are masked to
+// zero, as the im2row copy stores them (the blob's weights are zero there too, but 0 * NaN must not leak in).  Same blob, same k order, rows in the vertical
+// padding contribute exact zeros instead of being skipped: bit-identical to k_stem_im2row + k_stem_mfma.
+// ======================================================================================
+constexpr int kSrThreads = 256, kSrTH = 8, kSrTW = 32;
+
+struct StemRowsParams {
+    const float* x;
+    const _Float16* w;   // [KS][NT][64 lanes][8]
+    const float* bias;
+    float* y;
+    int N, H, W, C, O, KH, S, ph, pw, Ho, Wo;
+    int tiles_h, tiles_w;
+    int IH, IWC, row_h;  // halo tile: IH rows of IWC elements, row pitch row_h halfs (even, >= IWC + Rp - RL; the tail is zero)
+    int ksub, KS, RL;    // RL = KW * C: real elements of a tap row's run
+    uint32_t w_off;      // byte offset of the W fragments inside the dynamic LDS
+    ScaleDiv sd;
+    float s1, s2, s1x;
+    PostOp post;
+    uint32_t nblocks;
+};
+
+template <int FMT, int NT>
+__global__ __launch_bounds__(kSrThreads) void k_stem_rows(const StemRowsParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* sT = reinterpret_cast<uint32_t*>(smem);
+    _Float16* tile = reinterpret_cast<_Float16*>(smem + 64);   // [IH][row_h]
+    lut_fill<FMT>(sT);
+    {   // W: all k-steps resident
+        const int n16 = p.KS * NT * 64;
+        const uint4* src = reinterpret_cast<const uint4*>(p.w);
+        uint4* dst = reinterpret_cast<uint4*>(smem + p.w_off);
+        for (int i = threadIdx.x; i < n16; i += kSrThreads) dst[i] = src[i];
+    }
+    uint32_t b = xcd_remap(blockIdx.x, p.nblocks);
+    const int tw = b % p.tiles_w; b /= p.tiles_w;
+    const int th = b % p.tiles_h; b /= p.tiles_h;
+    const int n = b;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 15, kq = lane >> 4;
+    const int h_in0 = th * kSrTH * p.S - p.ph, w_in0 = tw * kSrTW * p.S - p.pw;
+    __syncthreads();  // LUT visible
+    {   // halo rows: coalesced dword loads, encode once, fp16 to LDS; the pitch's tail and out-of-image elements are zero
+        const float* xn = p.x + (size_t)n * p.H * p.W * p.C;
+        const int n_el = p.IH * p.row_h;
+        const int e_w0 = w_in0 * p.C;
+        const int row_el = p.W * p.C;
+        constexpr int U = 8;
+        for (int base = threadIdx.x; base < n_el; base += kSrThreads * U) {
+            float v[U];
+            int dst[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = base + u * kSrThreads;
+                const int ih = i / p.row_h, e = i - ih * p.row_h;
+                const int gh = h_in0 + ih, ge = e_w0 + e;
+                const bool live = i < n_el;
+                const bool inb = live && e < p.IWC && (unsigned)gh < (unsigned)p.H && ge >= 0 && ge < row_el;
+                dst[u] = live ? i : -1;
+                v[u] = xn[inb ? gh * row_el + ge : 0];   // unconditional (clamped) load
+                if (!inb) v[u] = 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (dst[u] >= 0) tile[dst[u]] = (_Float16)quantize_scaled<FMT, 4>(v[u], p.sd, sT);
+        }
+    }
+    float4 bqv[NT];
+    PostVec pvv[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int ch = j * 16 + kq * 4;
+        bqv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        pvv[j] = PostVec{make_float4(1.f, 1.f, 1.f, 1.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+        if (ch < p.O) {
+            if (p.bias) {
+                const float4 bb = *reinterpret_cast<const float4*>(p.bias + ch);
+                bqv[j] = make_float4(256.f * ((bb.x / p.s1) / p.s2), 256.f * ((bb.y / p.s1) / p.s2),
+                                     256.f * ((bb.z / p.s1) / p.s2), 256.f * ((bb.w / p.s1) / p.s2));
+            }
+            pvv[j] = post_load(p.post, ch);
+        }
+    }
+    __syncthreads();
+    const unsigned char* wl = smem + p.w_off + lane * 16;
+    // elements past the run (r >= KW*C) are neighbouring pixels' data: masked to +0 so that a NaN / Inf there cannot reach this
+    // pixel through 0 * NaN (the im2row form stores zeros there)
+    uint32_t rmask[2][4];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int dw = 0; dw < 4; ++dw) {
+            const int r0 = sub * 32 + kq * 8 + dw * 2;
+            rmask[sub][dw] = (r0 < p.RL ? 0x0000FFFFu : 0u) | (r0 + 1 < p.RL ? 0xFFFF0000u : 0u);
+        }
+    for (int u = wave; u < kSrTH * (kSrTW / 16); u += kSrThreads / 64) {
+        const int orow = u >> 1, seg = u & 1;
+        const int goh = th * kSrTH + orow, gow = tw * kSrTW + seg * 16 + col;
+        const uint32_t* origin = reinterpret_cast<const uint32_t*>(tile + (orow * p.S) * p.row_h + ((seg * 16 + col) * p.S) * p.C + kq * 8);
+        floatx4 acc[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+        for (int kh = 0; kh < p.KH; ++kh) {
+            for (int sub = 0; sub < p.ksub; ++sub) {
+                const uint32_t* src = origin + ((kh * p.row_h + sub * 32) >> 1);
+                typedef uint32_t u32x4r __attribute__((ext_vector_type(4)));
+                const half8 xf = __builtin_bit_cast(half8, u32x4r{src[0] & rmask[sub][0], src[1] & rmask[sub][1],
+                                                                  src[2] & rmask[sub][2], src[3] & rmask[sub][3]});
+                const unsigned char* wt = wl + (size_t)((kh * p.ksub + sub) * NT) * 1024;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const half8 wf = *reinterpret_cast<const half8*>(wt + j * 1024);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf, acc[j], 0, 0, 0);
+                }
+            }
+        }
+        if (goh < p.Ho && gow < p.Wo) {
+            float* yp = p.y + (((size_t)n * p.Ho + goh) * p.Wo + gow) * p.O;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int ch = j * 16 + kq * 4;
+                if (ch >= p.O) continue;
+                const float4 bq = bqv[j];
+                float4 r;
+                r.x = ((acc[j][0] + bq.x) * p.s1x) * p.s2;
+                r.y = ((acc[j][1] + bq.y) * p.s1x) * p.s2;
+                r.z = ((acc[j][2] + bq.z) * p.s1x) * p.s2;
+                r.w = ((acc[j][3] + bq.w) * p.s1x) * p.s2;
+                st_stream4<SLFP_NT_STEM_MFMA>(yp + ch, post_apply_v(r, p.post, pvv[j]));
+            }
+        }
+    }
+}
+
 // ---- host side ------------------------------------------------------------------------------
 static int stem_rp(const slfp_conv2d_desc& d) { return (int)ceil_div(d.kw * d.c_in, 32) * 32; }
 
@@ -200,8 +340,51 @@ static int launch_stem_mfma_t(const StemMfmaParams& p, size_t lds, unsigned grid
     return check_launch("slfp MFMA stem kernel");
 }
 
+// the fused form: even S*C (4-byte aligned fragment reads), everything in one workgroup's LDS
+static bool stem_rows_geometry(const slfp_conv2d_desc& d, StemRowsParams* p, size_t* lds, int* nt_out) {
+    if ((d.stride_w * d.c_in) % 2) return false;
+    int ksub, nt;
+    stem_mfma_blob_shape(d, &ksub, &nt);
+    const int rp = stem_rp(d), rl = (int)(d.kw * d.c_in);
+    p->IH = (kSrTH - 1) * d.stride_h + (int)d.kh;
+    p->IWC = ((kSrTW - 1) * d.stride_w + (int)d.kw) * (int)d.c_in;
+    p->row_h = (p->IWC + (rp - rl) + 1) & ~1;
+    p->ksub = ksub;
+    p->KS = (int)d.kh * ksub;
+    p->RL = rl;
+    p->w_off = (uint32_t)((64 + (size_t)p->IH * p->row_h * sizeof(_Float16) + 15) & ~(size_t)15);
+    *lds = p->w_off + (size_t)p->KS * nt * 1024;
+    *nt_out = nt;
+    return *lds <= 64 * 1024 && (int64_t)d.h * d.w * d.c_in < (1ll << 30);
+}
+
 int launch_stem_mfma(const slfp_conv2d_desc& d, const ConvPlan& plan, const float* x, const void* wblob,
                      const float* bias, const PostOp& post, float* y, void* workspace, hipStream_t stream) {
+    {
+        StemRowsParams q;
+        size_t lds;
+        int nt;
+        if (!switches().stem_im2row && stem_rows_geometry(d, &q, &lds, &nt)) {
+            q.x = x; q.w = reinterpret_cast<const _Float16*>(wblob); q.bias = bias; q.y = y; q.post = post;
+            q.N = (int)d.n; q.H = (int)d.h; q.W = (int)d.w; q.C = (int)d.c_in; q.O = (int)d.c_out; q.KH = (int)d.kh;
+            q.S = d.stride_h; q.ph = d.pad_h; q.pw = d.pad_w; q.Ho = (int)plan.h_out; q.Wo = (int)plan.w_out;
+            q.tiles_h = (int)ceil_div(q.Ho, kSrTH); q.tiles_w = (int)ceil_div(q.Wo, kSrTW);
+            q.sd = make_scale_div(d.ka, 4);
+            q.s1 = plan.s1; q.s2 = plan.s2; q.s1x = plan.s1 * (1.0f / 256.0f);
+            const int64_t nblocks = (int64_t)q.N * q.tiles_h * q.tiles_w;
+            if (nblocks > 0x7FFFFFFF) return fail(SLFP_ERR_UNSUPPORTED, "MFMA stem: grid too large");
+            q.nblocks = (uint32_t)nblocks;
+            const bool a8 = plan.fmt_act == kFmtAct8;
+            if (nt == 4) {
+                if (a8) hipLaunchKernelGGL((k_stem_rows<kFmtAct8, 4>), dim3(q.nblocks), dim3(kSrThreads), lds, stream, q);
+                else hipLaunchKernelGGL((k_stem_rows<kFmtSfp7, 4>), dim3(q.nblocks), dim3(kSrThreads), lds, stream, q);
+            } else {
+                if (a8) hipLaunchKernelGGL((k_stem_rows<kFmtAct8, 6>), dim3(q.nblocks), dim3(kSrThreads), lds, stream, q);
+                else hipLaunchKernelGGL((k_stem_rows<kFmtSfp7, 6>), dim3(q.nblocks), dim3(kSrThreads), lds, stream, q);
+            }
+            return check_launch("slfp MFMA stem (rows in LDS) kernel");
+        }
+    }
     if (!workspace) return fail(SLFP_ERR_BAD_ARG, "MFMA stem: workspace required (slfp_conv2d_workspace_bytes)");
     const int rp = stem_rp(d), rp_shift = rp == 32 ? 5 : 6;
     int ksub, nt;

@@ -1453,6 +1453,35 @@ def test_stem_float32_mfma_is_bit_identical_to_the_vector_kernel(lib, dev):
         L.slfp_debug_reload_switches()
 
 
+def test_large_kernel_stem_without_the_im2row_workspace_is_bit_identical(lib, dev):
+    """Round 3: the 7x7 stride-2 stems (ResNet-50 3 -> 64, SqueezeNet 3 -> 96 with bias) keep their encoded input rows in LDS
+    (k_stem_rows) instead of writing an im2row copy to the workspace: same blob, same k order -> the same bits as the two-kernel
+    form (SLFP_STEM_IM2ROW), ragged sizes and NaN inputs included; the oracle bar is checked by the geometry tests."""
+    L = lib.load()
+    gen = torch.Generator(device=dev).manual_seed(4242)
+    Ka, Kw = 0.17, 0.031
+    try:
+        for (O, bias, qbits), (n, h, w) in (((64, False, 8), (3, 224, 224)), ((96, True, 7), (2, 224, 224)), ((64, True, 8), (2, 75, 61))):
+            x = torch.randn((n, h, w, 3), generator=gen, device=dev) * (5.0 * Ka)
+            x.view(-1)[11::997] = float("nan")
+            wt = torch.randn((O, 3, 7, 7), generator=gen, device=dev) * (4.0 * Kw)
+            b = (torch.randn(O, generator=gen, device=dev) * 0.3) if bias else None
+            outs = []
+            for old in (False, True):
+                os.environ.pop("SLFP_STEM_IM2ROW", None)
+                if old:
+                    os.environ["SLFP_STEM_IM2ROW"] = "1"
+                L.slfp_debug_reload_switches()
+                y, kern = _raw_conv(lib, dev, x, wt, b, 2, 3, 1, Ka, Kw, qbits)
+                assert kern.startswith("stem_mfma"), kern
+                outs.append(y.cpu().numpy())
+            assert same_bits(outs[0], outs[1]), (O, bias, qbits, n, h, w)
+            assert np.isnan(outs[0]).any()
+    finally:
+        os.environ.pop("SLFP_STEM_IM2ROW", None)
+        L.slfp_debug_reload_switches()
+
+
 def test_three_pass_table_encoder_equals_long_form_for_all_2_32_inputs(lib, dev):
     """Round 3: the float32-equivalent pointwise mode (SLFP_MFMA_F16X3) now takes its hi / lo fp16 operand
     pair from two threshold tables (csrc/slfp_enc.hpp: enc2_f16_hl) instead of the 22-instruction long form + two
