@@ -361,8 +361,14 @@ def timed_steps(step, steps, world, dev):
     return time.perf_counter() - t0
 
 
-def run_config(L, net, batch, qbits, passes, steps, warmup, dev, rank, world, post=False, per_layer=False, exact_too=False):
-    """One workload: every Conv2d_Q layer of `net` at `batch` images on this rank.  Returns (result dict, per-rank seconds)."""
+def run_config(L, net, batch, qbits, passes, steps, warmup, dev, rank, world, post=False, per_layer=False, exact_too=False,
+               image_groups=1):
+    """One workload: every Conv2d_Q layer of `net` at `batch` images on this rank.  Returns (result dict, per-rank seconds).
+    image_groups = G > 1: the timed steps run the batch as G groups of batch / G images, each group on its own HIP stream
+    through all the layers (images are independent units of this path -- SURVEY 8e -- so the groups never synchronise: while
+    one group's kernel drains its last workgroups, another group's kernel fills the CUs; the per-launch gap of one stream is
+    the other's work).  Same weights (one prepared blob per layer), same images per step; the per-kernel figures of the
+    result are measured on whole-batch launches in a separate single-stream pass, which is also reported."""
     specs = layer_specs.conv_layers(net)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     layers = [Layer(L, s, batch, dev, passes, gen, qbits, post) for s in specs]
@@ -391,6 +397,29 @@ def run_config(L, net, batch, qbits, passes, steps, warmup, dev, rank, world, po
     dt_rank = timed_steps(step, steps, world, dev)
     rank_dts = sharding.rank_times(dt_rank, device=dev)   # every rank's seconds; the job's time is the slowest rank's
     dt = max(rank_dts)
+    single = None
+    if image_groups > 1 and batch % image_groups == 0:
+        single = {"value": round(batch * world * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4)}
+        groups = []
+        for g in range(image_groups):
+            st = torch.cuda.Stream(device=dev)
+            gl = [Layer(L, s, batch // image_groups, dev, passes, gen, qbits, post) for s in specs]
+            for a, b in zip(gl, layers):
+                a.blob = b.blob            # ONE prepared weight blob per layer, shared by the groups
+            groups.append((st.cuda_stream, gl))
+        torch.cuda.synchronize()
+
+        def gstep():
+            for i in range(len(specs)):    # the groups' launches interleaved layer by layer; the streams run free
+                for sh, gl in groups:
+                    gl[i].run(L, sh)
+
+        for _ in range(warmup):
+            gstep()
+        dt_rank = timed_steps(gstep, steps, world, dev)
+        rank_dts = sharding.rank_times(dt_rank, device=dev)
+        dt = max(rank_dts)
+        del groups
 
     # ---- per-kernel timing with HIP events on the launch stream (separate pass, same step order: cold caches)
     ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in layers] for _ in range(steps)]
@@ -475,6 +504,10 @@ def run_config(L, net, batch, qbits, passes, steps, warmup, dev, rank, world, po
         res["value_pointwise_f16x3_float32_equivalent"] = round(exact_value, 1)
     if scope is not None:
         res["dw_pw_scope"] = scope
+    if single is not None:
+        single["hbm_roofline_frac_whole_path"] = round(bytes_img * single["value"] / 1e9 / world / HBM_PEAK_GBS, 4)
+        res["single_stream"] = single
+        res["image_groups"] = image_groups
     if per_layer and rank == 0:
         for l, ms in zip(layers, layer_ms):
             sp = l.spec
@@ -655,6 +688,8 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of BASELINE configs 3-5 and the codec")
     ap.add_argument("--cpu-sample-batch", type=int, default=16)
     ap.add_argument("--per-layer", action="store_true", help="also print a per-layer table to stderr")
+    ap.add_argument("--image-groups", type=int, default=2,
+                    help="run a step's batch as this many independent image groups on as many HIP streams (1 = one stream)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -685,7 +720,7 @@ def main():
         raise SystemExit("--global-batch must divide evenly over the ranks (the bench reports one per-rank batch)")
 
     res, rank_dts = run_config(L, args.net, batch, args.qbits, args.passes, args.steps, args.warmup, dev, rank, world,
-                               post=args.post, per_layer=args.per_layer, exact_too=True)
+                               post=args.post, per_layer=args.per_layer, exact_too=True, image_groups=args.image_groups)
 
     if rank == 0:
         out = {
@@ -695,7 +730,10 @@ def main():
             "vs_baseline": None, "dtype": "f32 (1x1 contraction: fp16 MFMA operands, f32 accumulate)", "data": "synthetic",
             "config": {"workload": f"{args.net}: all {res['n_layers']} Conv2d_Q layers, "
                                    f"{'SLFP<3,4> Qbits=8' if args.qbits == 8 else 'SFP<3,3> Qbits=7'}, NHWC, "
-                                   f"batch {batch} per GPU, inputs resident in HBM",
+                                   f"batch {batch} per GPU"
+                                   + (f" as {res['image_groups']} concurrent image groups of {batch // res['image_groups']} on "
+                                      f"{res['image_groups']} HIP streams" if res.get("image_groups", 1) > 1 else "")
+                                   + ", inputs resident in HBM",
                        "batch_per_gpu": batch, "global_batch": batch * world,
                        "parallelism": f"batch-sharded x{world}, one-time RCCL broadcast of the u8 weight codes",
                        "pointwise_mfma": res["pointwise_mfma"]},
@@ -708,6 +746,9 @@ def main():
             out["value_pointwise_f16x3_float32_equivalent"] = res["value_pointwise_f16x3_float32_equivalent"]
         if "dw_pw_scope" in res:
             out["dw_pw_scope"] = res["dw_pw_scope"]
+        if "single_stream" in res:
+            out["single_stream"] = res["single_stream"]   # the same steps as 27 whole-batch launches on one stream
+            out["image_groups"] = res["image_groups"]
     if world == 1 and rank == 0:
         if not args.no_other_configs:
             # BASELINE configs 3-5 at their named batch sizes: short runs (3 steps), each with its own roofline object

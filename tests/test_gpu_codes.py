@@ -450,6 +450,25 @@ def test_link_codes_whole_net_is_bit_identical_to_the_fused_net(dev, qbits):
         assert torch.equal(g(x).view(torch.int32), y_fused.view(torch.int32))
 
 
+def test_image_groups_on_two_streams_return_the_same_logits(dev):
+    """streams.forward_image_groups: the batch as two independent halves on two HIP streams through the whole fused / linked
+    MobileNetV1 == the single forward, bit for bit (images are independent units; the modules' plan / workspace caches are
+    keyed by stream)."""
+    from cnns_slfp_quantization_amd import fusion, streams
+    net, x, gold = _mobilenet224(dev, 8, 16)
+    with torch.no_grad():
+        fusion.fuse_bn_relu(net)
+        y1 = net(x)
+        for g in (2, 3):
+            yg = streams.forward_image_groups(net, x, groups=g)
+            torch.cuda.synchronize()
+            assert torch.equal(yg.view(torch.int32), y1.view(torch.int32)), g
+        assert fusion.link_codes(net, x) == 26
+        yc = streams.forward_image_groups(net, x, groups=2)
+        torch.cuda.synchronize()
+        assert torch.equal(yc.view(torch.int32), y1.view(torch.int32))
+
+
 def test_linked_modules_refuse_training(dev):
     from cnns_slfp_quantization_amd import fusion
     net, x, _ = _mobilenet224(dev, 8)
