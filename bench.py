@@ -755,8 +755,9 @@ def main():
             other = {}
             for net, b, q in OTHER_CONFIGS:
                 try:
-                    r, _ = run_config(L, net, b, q, 0, 3, 1, dev, 0, 1)
+                    r, _ = run_config(L, net, b, q, 0, 3, 1, dev, 0, 1, image_groups=args.image_groups)
                     other[net] = {"batch": b, "qbits": q, "value": r["value"], "unit": "images/sec", "ms_per_step": r["ms_per_step"],
+                                  "image_groups": r.get("image_groups", 1), "single_stream": r.get("single_stream"),
                                   "hbm_roofline_frac_whole_path": r["hbm_roofline_frac_whole_path"], "roofline": r["roofline"],
                                   "kernels": r["kernels"]}
                     if net == "vgg16_224":   # the conv -> conv hand-overs inside VGG-16's stages as 1-byte codes (dense kernels)
