@@ -518,7 +518,7 @@ def run_config(L, net, batch, qbits, passes, steps, warmup, dev, rank, world, po
     return res, rank_dts
 
 
-def run_codes_config(L, net, batch, qbits, steps, warmup, dev):
+def run_codes_config(L, net, batch, qbits, steps, warmup, dev, image_groups=1):
     """The same conv layers with 1-byte activation codes on every hand-over fusion.link_codes can make (SURVEY 8f rank 1,
     second half; slfp_conv2d_fwd_codes_ws): every layer with the fused BatchNorm + ReLU epilogue; MobileNetV1: ONE chain, the stem
     reading float32 images and writing the next layer's codes, every other layer reading codes (of its own synthetic input,
@@ -561,10 +561,19 @@ def run_codes_config(L, net, batch, qbits, steps, warmup, dev):
             y_codes[i] = x_codes[i + 1] = True
     if not any(y_codes):
         return None
-    layers = []
-    for i, s in enumerate(specs):
-        l = Layer(L, s, batch, dev, _lib.MFMA_F16X1, gen, qbits, post=True)
-        l.prepare(L, stream)
+    def make_layers(nb, share=None):
+        out_layers = []
+        for i, s in enumerate(specs):
+            l = Layer(L, s, nb, dev, _lib.MFMA_F16X1, gen, qbits, post=True)
+            if share is not None:
+                l.blob, l.post, l.bias = share[i].blob, share[i].post, share[i].bias   # one set of weights / BN vectors
+            else:
+                l.prepare(L, stream)
+            _finish_layer(l, i, s, nb)
+            out_layers.append(l)
+        return out_layers
+
+    def _finish_layer(l, i, s, nb):
         l.io = _lib.ConvIo(x_codes=1 if x_codes[i] else 0, y_codes=1 if y_codes[i] else 0,
                            y_ka=float(np.float32(specs[i + 1].Ka)) if y_codes[i] else 1.0, y_qbits=qbits)
         l.on_codes = x_codes[i] or y_codes[i]
@@ -574,20 +583,22 @@ def run_codes_config(L, net, batch, qbits, steps, warmup, dev):
             l.x = xc
         if y_codes[i]:
             l.y = torch.empty(l.y.shape, dtype=torch.uint8, device=dev)
-        l.cbytes = batch * (s.in_elems * (1 if x_codes[i] else 4) + s.out_elems * (1 if y_codes[i] else 4)) + 4 * s.w_elems
+        l.cbytes = nb * (s.in_elems * (1 if x_codes[i] else 4) + s.out_elems * (1 if y_codes[i] else 4)) + 4 * s.w_elems
         base = "stem" if s.c_in == 3 else ("dw3x3" if s.groups > 1 else ("pw_mfma" if s.k == (1, 1) else "dense_mfma"))
         l.family = base + ("_codes" if l.on_codes else "_float32")
-        layers.append(l)
+
+    layers = make_layers(batch)
     torch.cuda.synchronize()
 
-    def run(l):
-        if not l.on_codes:   # a layer with float32 on both sides (VGG-16's first stage): the float32 interface
-            l.run(L, stream)
+    def run(l, sh=None):
+        sh = stream if sh is None else sh
+        if not l.on_codes:   # a layer with float32 on both sides: the float32 interface
+            l.run(L, sh)
             return
         rc = L.slfp_conv2d_fwd_codes_ws(ctypes.byref(l.desc), ctypes.byref(l.io), l.x.data_ptr(), l.blob.data_ptr(),
                                         l.bias.data_ptr() if l.bias is not None else None,
                                         l.post[0].data_ptr(), l.post[1].data_ptr(), 1, l.y.data_ptr(),
-                                        l.ws.data_ptr() if l.ws is not None else None, stream)
+                                        l.ws.data_ptr() if l.ws is not None else None, sh)
         if rc != 0:
             _lib.check(rc)
 
@@ -598,6 +609,21 @@ def run_codes_config(L, net, batch, qbits, steps, warmup, dev):
     for _ in range(warmup):
         step()
     dt = timed_steps(step, steps, 1, dev)
+    single = None
+    if image_groups > 1 and batch % image_groups == 0:   # the batch as independent image groups on as many HIP streams (run_config)
+        single = {"value": round(batch * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4)}
+        groups = [(torch.cuda.Stream(device=dev).cuda_stream, make_layers(batch // image_groups, share=layers)) for _ in range(image_groups)]
+        torch.cuda.synchronize()
+
+        def gstep():
+            for i in range(len(specs)):
+                for sh, gl in groups:
+                    run(gl[i], sh)
+
+        for _ in range(warmup):
+            gstep()
+        dt = timed_steps(gstep, steps, 1, dev)
+        del groups
     ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in layers] for _ in range(steps)]
     for k in range(steps):
         for i, l in enumerate(layers):
@@ -619,6 +645,7 @@ def run_codes_config(L, net, batch, qbits, steps, warmup, dev):
     bytes_img = sum(l.cbytes for l in layers) / batch
     f32_bytes_img = layer_specs.algorithmic_bytes_per_image(net, batch)
     res = {"value": round(value, 1), "unit": "images/sec", "ms_per_step": round(dt / steps * 1e3, 4),
+           "image_groups": image_groups if single is not None else 1, "single_stream": single,
            "algorithmic_bytes_per_image": int(bytes_img),
            "hbm_roofline_frac_whole_path": round(bytes_img * value / 1e9 / HBM_PEAK_GBS, 4),
            "float32_interface_bytes_equivalent_frac": round(f32_bytes_img * value / 1e9 / HBM_PEAK_GBS, 4),
@@ -763,13 +790,15 @@ def main():
                     if net == "vgg16_224":   # the conv -> conv hand-overs inside VGG-16's stages as 1-byte codes (dense kernels)
                         cp = run_codes_config(L, net, b, q, 3, 1, dev)
                         if cp:
-                            other[net]["codes_path"] = {k: cp[k] for k in ("value", "unit", "ms_per_step", "algorithmic_bytes_per_image", "kernels")}
+                            other[net]["codes_path"] = {k: cp[k] for k in ("value", "unit", "ms_per_step", "image_groups", "single_stream",
+                                                                           "algorithmic_bytes_per_image", "kernels")}
                 except Exception as e:  # a secondary measurement must not take the headline line down
                     other[net] = {"batch": b, "qbits": q, "error": str(e)[:200]}
             out["other_configs"] = other
             out["codec"] = codec_bench(L, dev)
         if args.net in ("mobilenetv1_imagenet224", "vgg16_224") and args.passes in (0, 1) and not args.post:
             try:   # secondary measurement: the same layers chained through 1-byte codes
+                # (one stream: the code kernels' persistent grids already fill the device; two image groups measured 180 k vs 206 k)
                 cp = run_codes_config(L, args.net, batch, args.qbits, args.steps, args.warmup, dev)
                 if cp:
                     out["codes_path"] = cp
