@@ -361,6 +361,20 @@ def timed_steps(step, steps, world, dev):
     return time.perf_counter() - t0
 
 
+_GROUP_STREAMS = {}
+
+
+def group_stream(dev, g):
+    """The HIP stream of image group g: created once per process and reused by every measurement.  (HIP maps streams to a few
+    hardware queues; two streams that land on the same queue serialise -- profiles/two_streams.py measured 110 k images/s on a
+    freshly created SECOND pair of streams against 129 k on the first pair -- so the groups keep the first streams the
+    process creates, which every run so far placed on different queues.)"""
+    key = (dev.index, g)
+    if key not in _GROUP_STREAMS:
+        _GROUP_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _GROUP_STREAMS[key]
+
+
 def run_config(L, net, batch, qbits, passes, steps, warmup, dev, rank, world, post=False, per_layer=False, exact_too=False,
                image_groups=1):
     """One workload: every Conv2d_Q layer of `net` at `batch` images on this rank.  Returns (result dict, per-rank seconds).
@@ -402,7 +416,7 @@ def run_config(L, net, batch, qbits, passes, steps, warmup, dev, rank, world, po
         single = {"value": round(batch * world * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4)}
         groups = []
         for g in range(image_groups):
-            st = torch.cuda.Stream(device=dev)
+            st = group_stream(dev, g)
             gl = [Layer(L, s, batch // image_groups, dev, passes, gen, qbits, post) for s in specs]
             for a, b in zip(gl, layers):
                 a.blob = b.blob            # ONE prepared weight blob per layer, shared by the groups
@@ -612,7 +626,7 @@ def run_codes_config(L, net, batch, qbits, steps, warmup, dev, image_groups=1):
     single = None
     if image_groups > 1 and batch % image_groups == 0:   # the batch as independent image groups on as many HIP streams (run_config)
         single = {"value": round(batch * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4)}
-        groups = [(torch.cuda.Stream(device=dev).cuda_stream, make_layers(batch // image_groups, share=layers)) for _ in range(image_groups)]
+        groups = [(group_stream(dev, g).cuda_stream, make_layers(batch // image_groups, share=layers)) for g in range(image_groups)]
         torch.cuda.synchronize()
 
         def gstep():

@@ -31,8 +31,11 @@ def _streams(device, n):
     return st
 
 
-def forward_image_groups(model, x, groups=2):
-    """model(x) computed as `groups` independent slices of the batch, one HIP stream each.  `x`: a ROCm ('cuda') tensor with the
+def forward_image_groups(model, x, groups=2, streams=None):
+    """model(x) computed as `groups` independent slices of the batch, one HIP stream each (`streams`: the torch.cuda.Stream
+    objects to use; default: created once per device and group count).  HIP maps streams to a handful of hardware queues and two
+    streams that share a queue serialise (profiles/stream_pairs.py: of the 28 pairs among a process's first eight streams five
+    do -- 107 k instead of 126 k images/s); the first two streams a process creates have always landed on different queues.  `x`: a ROCm ('cuda') tensor with the
     batch in dimension 0; the model must treat images independently (inference: eval-mode BatchNorm).  The caller's current
     stream waits for all groups before the result is returned.  Returns the concatenated outputs (a tensor, or a tuple of
     tensors if the model returns a tuple)."""
@@ -47,7 +50,7 @@ def forward_image_groups(model, x, groups=2):
     ready.record(cur)
     bounds = [(n * g) // groups for g in range(groups + 1)]
     outs, done = [], []
-    for g, st in enumerate(_streams(x.device, groups)):
+    for g, st in enumerate(streams if streams is not None else _streams(x.device, groups)):
         st.wait_event(ready)                       # x (and the weights) are complete on the caller's stream
         with torch.cuda.stream(st):
             xg = x[bounds[g]:bounds[g + 1]]

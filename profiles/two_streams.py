@@ -27,10 +27,12 @@ JOIN = os.environ.get("JOIN", "0") == "1"   # fork / join per layer: what a drop
 
 def timed(groups, steps=200, warm=100):
     evs = [torch.cuda.Event() for _ in groups]
+    OFF = int(os.environ.get("OFFSET", "0"))   # group g runs OFF * g layers behind group 0 (pairs big layers with small ones)
     def step():
-        for i in range(len(specs)):            # interleave the groups' launches layer by layer
-            for st, layers in groups:
-                layers[i].run(L, st.cuda_stream)
+        nl = len(specs)
+        for i in range(nl):            # interleave the groups' launches layer by layer
+            for gi, (st, layers) in enumerate(groups):
+                layers[(i - OFF * gi) % nl].run(L, st.cuda_stream)
             if JOIN and len(groups) > 1:
                 for (st, _), ev in zip(groups, evs):
                     ev.record(st)
