@@ -367,8 +367,8 @@ _GROUP_STREAMS = {}
 def group_stream(dev, g):
     """The HIP stream of image group g: created once per process and reused by every measurement.  (HIP maps streams to a few
     hardware queues; two streams that land on the same queue serialise -- profiles/two_streams.py measured 110 k images/s on a
-    freshly created SECOND pair of streams against 129 k on the first pair -- so the groups keep the first streams the
-    process creates, which every run so far placed on different queues.)"""
+    freshly created SECOND pair of streams against 129 k on the first pair -- so the streams are kept for the process, and
+    run_config tries the pairs among the first four once and keeps one that overlaps.)"""
     key = (dev.index, g)
     if key not in _GROUP_STREAMS:
         _GROUP_STREAMS[key] = torch.cuda.Stream(device=dev)
@@ -420,13 +420,34 @@ def run_config(L, net, batch, qbits, passes, steps, warmup, dev, rank, world, po
             gl = [Layer(L, s, batch // image_groups, dev, passes, gen, qbits, post) for s in specs]
             for a, b in zip(gl, layers):
                 a.blob = b.blob            # ONE prepared weight blob per layer, shared by the groups
-            groups.append((st.cuda_stream, gl))
+            groups.append([st.cuda_stream, gl])
         torch.cuda.synchronize()
 
         def gstep():
             for i in range(len(specs)):    # the groups' launches interleaved layer by layer; the streams run free
                 for sh, gl in groups:
                     gl[i].run(L, sh)
+
+        if image_groups == 2 and (dev.index, "pair") not in _GROUP_STREAMS:
+            # two streams that HIP placed on one hardware queue serialise (profiles/stream_pairs.py): try the pairs among four
+            # candidate streams for a few steps each, once per process, and keep the pair that overlaps
+            cand = [group_stream(dev, g) for g in range(4)]
+            best = None
+            for a, b in ((0, 1), (2, 3), (0, 2), (1, 3), (0, 3), (1, 2)):
+                groups[0][0], groups[1][0] = cand[a].cuda_stream, cand[b].cuda_stream
+                gstep()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(4):
+                    gstep()
+                torch.cuda.synchronize()
+                t = time.perf_counter() - t0
+                if best is None or t < best[0]:
+                    best = (t, a, b)
+            _GROUP_STREAMS[(dev.index, "pair")] = (cand[best[1]], cand[best[2]])
+        if image_groups == 2:
+            pa, pb = _GROUP_STREAMS[(dev.index, "pair")]
+            groups[0][0], groups[1][0] = pa.cuda_stream, pb.cuda_stream
 
         for _ in range(warmup):
             gstep()
