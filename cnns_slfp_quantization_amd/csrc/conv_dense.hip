@@ -155,14 +155,18 @@ __global__ __launch_bounds__(256) void k_dense_decode(const uint8_t* __restrict_
 // float32 stores (16 bytes per lane: 4 consecutive channels of one pixel) or the consumer's 1-byte codes.  Code output: the 4
 // channel tiles of a wave are encoded, transposed across the lane quarters (rows_transpose4) so that a lane holds 16
 // CONSECUTIVE channels of its pixel, and stored as one 16-byte piece.
-template <int MT>
+// TAB_READY: the code table already sits at `smem` (k_dense3x3_res keeps it next to its operand tiles); otherwise it is filled
+// over the dead operand tiles here.
+template <int MT, bool TAB_READY = false>
 __device__ __forceinline__ void dense_epilogue(const DenseParams& p, const floatx4 (&acc)[MT][4], unsigned char* smem, int n, int th,
                                                int tw, int TH, int wm, int wn, int nt0, int col, int kq) {
     const int gow = tw * kDnTW + col;
     if (p.yc) {
-        __syncthreads();   // every wave has left the main loop: the operand tiles in LDS are dead
-        enc_fill<kDnThreads>(reinterpret_cast<uint2*>(smem), p.enc_out);
-        __syncthreads();
+        if constexpr (!TAB_READY) {
+            __syncthreads();   // every wave has left the main loop: the operand tiles in LDS are dead
+            enc_fill<kDnThreads>(reinterpret_cast<uint2*>(smem), p.enc_out);
+            __syncthreads();
+        }
         const float r1 = p.enc_out.r1, lo = p.enc_out.lo, hi = p.enc_out.hi;
         const int chw = (nt0 + wn * 4) * 16;   // this wave's 64 channels
         float4 bq[4];
@@ -570,6 +574,151 @@ __global__ __launch_bounds__(kDnThreads, (MT == 4 ? 2 : 4)) void k_dense3x3(cons
     dense_epilogue<MT>(p, acc, smem, n, th, tw, TH, wm, wn, nt0, col, kq);
 }
 
+// ======================================================================================
+// k_dense3x3_res: 3x3, stride 1, single pass, C_in <= 64 (ONE 64-channel chunk): VGG-16's conv1_2 / conv2_1, ResNet-50's
+// layer1 3x3s, SqueezeNet's expand3x3 -- end of round 3.  With one chunk the nine tap tiles of a 64-channel output slice are
+// all the weights there are (72 KiB): k_dense3x3 re-staged them for every 128-pixel tile (72 KiB of W next to 23 KiB of halo
+// through the DMA path, one barrier per tap around 8 MFMAs per wave: profiles/r03d_vgg16, 64 -> 64 @224 1.09 ms, mfma_busy
+// 0.19).  Here a PERSISTENT workgroup keeps them resident in LDS and walks over its share of the output tiles: per tile one
+// halo DMA (into the second buffer, issued before the MFMAs of the current tile), 9 taps of MFMAs without a barrier, ONE
+// barrier, then the stores -- which stay in flight under the next tile's MFMAs because the wait that publishes the next
+// halo comes before them in the instruction stream.  Same fragment layout, same MFMA order: bit-identical to k_dense3x3.
+//   workgroup = 8 waves x MT rows x 16 columns x 64 output channels; LDS = 72 KiB W + 2 halos + the code table.
+// ======================================================================================
+template <int MT, int NSLOT>
+__global__ __launch_bounds__(kDnThreads, 2) void k_dense3x3_res(const DenseParams p) {
+    constexpr int TH = 8 * MT, WT = 64 * 128;
+    constexpr int IW = kDnTW + 2, IH = TH + 2, NPIX = IH * IW, PIECES = (NPIX + 7) / 8;
+    static_assert((PIECES + 7) / 8 <= NSLOT, "halo slots");
+    constexpr uint32_t xbytes = (uint32_t)PIECES * 1024u;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* wres = smem;                 // [9 taps][WT]
+    unsigned char* xsb = smem + 9 * WT;         // [2][PIECES KiB]
+    unsigned char* tab = xsb + 2 * xbytes;      // code table of the consumer (kEncEntries * 8 bytes)
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 15, kq = lane >> 4;
+    // grid = gs spatial walkers x n_blocks channel slices; a walker's tiles: one of R contiguous ranges (R = 8: neighbouring
+    // tiles, which share halo columns / rows, on one XCD's L2 when there is a single channel slice), strided inside it
+    const uint32_t nbk = (uint32_t)p.n_blocks;
+    const uint32_t gs = gridDim.x / nbk;
+    const int nb = (int)(blockIdx.x % nbk);
+    const uint32_t sb = blockIdx.x / nbk;
+    const uint32_t T = (uint32_t)p.N * p.tiles_h * p.tiles_w;
+    const uint32_t R = (gs % 8u == 0u) ? 8u : 1u;
+    const uint32_t per_r = (T + R - 1) / R;
+    const uint32_t r_end = min(T, (sb % R + 1) * per_r);
+    const uint32_t t_step = gs / R;
+    uint32_t tile = (sb % R) * per_r + sb / R;
+    if (tile >= r_end) return;   // whole workgroup (uniform)
+
+    // halo slots of this lane: pixel -> (ih, iw, source chunk), fixed for every tile
+    const unsigned char* zp = p.zero_page + (lane & 7) * 16;
+    uint32_t slot[NSLOT];
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j) {
+        const int pc = wave + 8 * j;
+        const int pix = pc * 8 + (lane >> 3);
+        const int ih = pix / IW, iw = pix - ih * IW;
+        const int c16 = (lane & 7) ^ (((pix >> 1) & 3) << 1);
+        slot[j] = (pc < PIECES && pix < NPIX) ? (uint32_t)(ih << 16 | iw << 8 | c16) : 0xFFFFFFFFu;
+    }
+    auto stage_tile = [&](uint32_t t, int buf) {
+        const int tw = (int)(t % (uint32_t)p.tiles_w);
+        const uint32_t t2 = t / (uint32_t)p.tiles_w;
+        const int th = (int)(t2 % (uint32_t)p.tiles_h);
+        const int n = (int)(t2 / (uint32_t)p.tiles_h);
+        const int h0 = th * TH - p.ph, w0 = tw * kDnTW - p.pw;
+        const unsigned char* xen = reinterpret_cast<const unsigned char*>(p.xe) + (size_t)n * p.H * p.W * 128;
+#pragma unroll
+        for (int j = 0; j < NSLOT; ++j) {
+            const int pc = wave + 8 * j;
+            if (pc < PIECES) {   // wave-uniform
+                const int gh = h0 + (int)(slot[j] >> 16), gw = w0 + (int)((slot[j] >> 8) & 0xFF);
+                const bool inb = slot[j] != 0xFFFFFFFFu && (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W;
+                const unsigned char* src = inb ? xen + ((uint32_t)(gh * p.W + gw) * 128u + (slot[j] & 0xFF) * 16u) : zp;
+                glds16(src, xsb + (size_t)buf * xbytes + (size_t)pc * 1024);
+            }
+        }
+    };
+
+    // ---- all nine tap tiles of this channel slice: 72 pieces of 1 KiB, 9 per wave
+    const int nt0 = nb * 4;
+    {
+        const size_t w_tap_stride = (size_t)p.n_tiles * p.KS * 1024;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const int pq = wave * 9 + q;
+            const int tap = pq >> 3, pc = pq & 7;           // piece = (channel tile pc >> 1, k-step pc & 1)
+            int nt = nt0 + (pc >> 1);
+            nt = nt < p.n_tiles ? nt : p.n_tiles - 1;       // tiles past C_out: clamp (results never stored)
+            glds16(reinterpret_cast<const unsigned char*>(p.w) + (size_t)tap * w_tap_stride + ((size_t)nt * p.KS + (pc & 1)) * 1024 + (size_t)lane * 16,
+                   wres + (size_t)pq * 1024);
+        }
+    }
+    stage_tile(tile, 0);
+    if (p.yc) enc_fill<kDnThreads>(reinterpret_cast<uint2*>(tab), p.enc_out);
+
+    uint32_t xo[MT + 2][3];
+#pragma unroll
+    for (int r = 0; r < MT + 2; ++r)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) xo[r][kw] = dn_x_off((wave * MT + r) * IW + col + kw, kq);
+    const uint32_t wlane = (uint32_t)lane * 16u;
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int xb = 0;
+    for (;;) {
+        const uint32_t next = tile + t_step;
+        const bool has_next = next < r_end;
+        if (has_next) stage_tile(next, xb ^ 1);   // every wave left that buffer before the last barrier
+        floatx4 acc[MT][4];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+        const uint32_t xs_off = (uint32_t)(9 * WT) + (uint32_t)xb * xbytes;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int kh = tap / 3, kw = tap % 3;
+            const unsigned char* wt = wres + (size_t)tap * WT + wlane;
+            half8 wf[2][4], xf[2][MT];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wf[ks][j] = *reinterpret_cast<const half8*>(wt + j * 2048 + ks * 1024);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                uint32_t o0 = xs_off + xo[i + kh][kw];
+                asm volatile("" : "+v"(o0));
+                xf[0][i] = *reinterpret_cast<const half8*>(smem + o0);
+                xf[1][i] = *reinterpret_cast<const half8*>(smem + (o0 ^ 64u));
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][j], xf[ks][i], acc[i][j], 0, 0, 0);
+        }
+        // the next halo has had the whole tile to land; the stores of the previous tile are older still
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        {
+            const int tw = (int)(tile % (uint32_t)p.tiles_w);
+            const uint32_t t2 = tile / (uint32_t)p.tiles_w;
+            const int th = (int)(t2 % (uint32_t)p.tiles_h);
+            const int n = (int)(t2 / (uint32_t)p.tiles_h);
+            dense_epilogue<MT, true>(p, acc, tab, n, th, tw, TH, wave, 0, nt0, col, kq);
+        }
+        if (!has_next) break;
+        tile = next;
+        xb ^= 1;
+    }
+}
+
 // ---- host side: pick the tiling ----------------------------------------------------------
 struct DenseCfg { int wm, wn, mt; };
 // instantiated tilings, widest first
@@ -678,6 +827,37 @@ static int launch_dense_t(DenseParams& p, size_t lds, int planes, hipStream_t st
     return planes == 2 ? launch_dense_tp<WM, WN, MT, 3>(p, lds, stream, 2) : launch_dense_tp<WM, WN, MT, 1>(p, lds, stream, nwb);
 }
 
+// ---- the weights-resident persistent form (k_dense3x3_res)
+static bool dense_res_applicable(const slfp_conv2d_desc& d, int planes, int cp) {
+    return planes == 1 && cp == 64 && d.kh == 3 && d.kw == 3 && d.stride_h == 1 && d.pad_h <= 1 && d.pad_w <= 1 &&
+           !switches().dense_generic && switches().dense_res && switches().dense_cfg == 0;
+}
+
+template <int MT, int NSLOT>
+static int launch_dense_res_t(DenseParams& p, hipStream_t stream) {
+    constexpr int TH = 8 * MT, PIECES = ((TH + 2) * (kDnTW + 2) + 7) / 8;
+    const size_t lds = 9 * 8192 + 2 * (size_t)PIECES * 1024 + ((kEncEntries * 8 + 63) & ~63);
+    p.tiles_h = (int)ceil_div(p.Ho, TH);
+    p.n_blocks = (int)ceil_div((int64_t)p.O, 64);
+    const int64_t T = (int64_t)p.N * p.tiles_h * p.tiles_w;
+    if (T > 0x7FFFFFFF) return fail(SLFP_ERR_UNSUPPORTED, "dense MFMA conv: grid too large");
+    int64_t gs = std::min<int64_t>(T, std::max<int64_t>(1, device_cu_count() / p.n_blocks));   // one workgroup per CU (LDS)
+    if (gs >= 8) gs -= gs % 8;
+    auto fn = k_dense3x3_res<MT, NSLOT>;
+    const int rc = raise_lds_limit(reinterpret_cast<const void*>(fn), 160 * 1024);
+    if (rc != SLFP_OK) return rc;
+    p.nblocks = (uint32_t)(gs * p.n_blocks);
+    hipLaunchKernelGGL(fn, dim3(p.nblocks), dim3(kDnThreads), lds, stream, p);
+    return check_launch("slfp dense MFMA conv kernel (resident weights)");
+}
+
+static int launch_dense_res(DenseParams& p, hipStream_t stream) {
+    // 16-row tiles (two MFMA rows per W fragment read) unless they pad the image noticeably more than 8-row tiles
+    const int64_t pad16 = ceil_div(p.Ho, 16) * 16, pad8 = ceil_div(p.Ho, 8) * 8;
+    if (pad16 * 100 <= pad8 * 108) return launch_dense_res_t<2, 6>(p, stream);
+    return launch_dense_res_t<1, 3>(p, stream);
+}
+
 // code interface: is there a dense kernel for this layer with code input / output?  (the float32-interface kernel with a decode
 // pre-pass instead of the encode pre-pass and / or the code epilogue: same tilings, same results)
 bool dense_codes_applicable(const slfp_conv2d_desc& d, const ConvPlan& plan, int post_flags, bool y_codes) {
@@ -747,6 +927,7 @@ int launch_dense_mfma_io(const slfp_conv2d_desc& d, const ConvPlan& plan, const 
     const int64_t nblocks = (int64_t)p.N * p.tiles_h * p.tiles_w * p.n_blocks;
     if (nblocks > 0x7FFFFFFF) return fail(SLFP_ERR_UNSUPPORTED, "dense MFMA conv: grid too large");
     p.nblocks = (uint32_t)nblocks;
+    if (dense_res_applicable(d, planes, cp)) return launch_dense_res(p, stream);
     switch (g.cfg.wm * 100 + g.cfg.wn * 10 + g.cfg.mt) {
         case 244: return launch_dense_t<2, 4, 4>(p, g.lds, planes, stream, g.nwb);
         case 424: return launch_dense_t<4, 2, 4>(p, g.lds, planes, stream, g.nwb);

@@ -1482,6 +1482,50 @@ def test_large_kernel_stem_without_the_im2row_workspace_is_bit_identical(lib, de
         L.slfp_debug_reload_switches()
 
 
+def test_resident_weight_dense_kernel_is_bit_identical_to_the_per_tile_form(lib, dev):
+    """End of round 3: 3x3 stride-1 layers with C_in <= 64 (VGG-16 conv1_2 / conv2_1, ResNet-50 layer1, SqueezeNet expand3x3) run
+    on a persistent workgroup that keeps all nine tap tiles of its 64-channel slice in LDS (k_dense3x3_res) instead of
+    re-staging them per output tile: same fragments, same MFMA order -> the same bits as k_dense3x3 (SLFP_DENSE_NORES), on
+    16-row and 8-row tiles, several channel slices, ragged sizes, C_in / C_out that are not multiples of 64, no padding, NaN
+    inputs, more tiles than workgroups (batch 40 @ 56: 1120 tiles on 256 walkers), and against the oracle."""
+    L = lib.load()
+    gen = torch.Generator(device=dev).manual_seed(9090)
+    Ka, Kw = 0.21, 0.027
+    try:
+        cases = (  # c_in, c_out, n, h, w, pad, bias, qbits
+            (64, 64, 2, 224, 224, 1, False, 8), (64, 128, 3, 112, 112, 1, True, 8), (64, 64, 40, 56, 56, 1, False, 8),
+            (48, 192, 3, 27, 27, 1, True, 7), (16, 64, 2, 55, 55, 1, False, 7), (64, 72, 2, 13, 29, 1, False, 8),
+            (32, 256, 1, 19, 17, 0, True, 8), (64, 64, 1, 5, 5, 1, False, 8))
+        for ci, co, n, h, w, pad, bias, qbits in cases:
+            x = torch.relu(torch.randn((n, h, w, ci), generator=gen, device=dev)) * (5.0 * Ka)
+            x.view(-1)[13::1009] = float("nan")
+            wt = torch.randn((co, ci, 3, 3), generator=gen, device=dev) * (4.0 * Kw)
+            b = (torch.randn(co, generator=gen, device=dev) * 0.3) if bias else None
+            outs = []
+            for old in (False, True):
+                os.environ.pop("SLFP_DENSE_NORES", None)
+                if old:
+                    os.environ["SLFP_DENSE_NORES"] = "1"
+                L.slfp_debug_reload_switches()
+                y, kern = _raw_conv(lib, dev, x, wt, b, 1, pad, 1, Ka, Kw, qbits)
+                assert kern.startswith("dense_mfma"), kern
+                outs.append(y.cpu().numpy())
+            assert same_bits(outs[0], outs[1]), (ci, co, n, h, w, pad, bias, qbits)
+            assert np.isnan(outs[0]).any()
+        os.environ.pop("SLFP_DENSE_NORES", None)
+        L.slfp_debug_reload_switches()
+        # against the oracle (clean input, two images of a ragged case)
+        x = torch.relu(torch.randn((2, 21, 37, 64), generator=gen, device=dev)) * (5.0 * Ka)
+        wt = torch.randn((128, 64, 3, 3), generator=gen, device=dev) * (4.0 * Kw)
+        y, kern = _raw_conv(lib, dev, x, wt, None, 1, 1, 1, Ka, Kw, 8)
+        ref = so.conv2d(x.cpu().numpy().transpose(0, 3, 1, 2), wt.cpu().numpy(), None, 1, 1, 1, 1, np.float64(np.float32(Ka)), np.float64(np.float32(Kw)), 8)
+        got = y.cpu().numpy().transpose(0, 3, 1, 2)
+        assert np.abs(got - ref).max() <= _tol(kern) * np.abs(ref).max(), np.abs(got - ref).max() / np.abs(ref).max()
+    finally:
+        os.environ.pop("SLFP_DENSE_NORES", None)
+        L.slfp_debug_reload_switches()
+
+
 def test_three_pass_table_encoder_equals_long_form_for_all_2_32_inputs(lib, dev):
     """Round 3: the float32-equivalent pointwise mode (SLFP_MFMA_F16X3) now takes its hi / lo fp16 operand
     pair from two threshold tables (csrc/slfp_enc.hpp: enc2_f16_hl) instead of the 22-instruction long form + two
