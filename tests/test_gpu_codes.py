@@ -227,6 +227,29 @@ def test_dense_layers_on_codes_are_bit_identical_to_the_float32_interface(lib, d
     assert L.slfp_conv2d_codes_supported(ctypes.byref(d), ctypes.byref(io), 0, 1) == 1
 
 
+def test_resident_weight_dense_kernel_with_alternating_wave_groups_writes_the_same_codes(lib, dev):
+    """k_dense3x3_res<DEPHASE>: on long walks with code output the second wave of every SIMD runs the previous tile's epilogue
+    before its MFMAs (csrc/conv_dense.hip).  Sizes past the switch-over (>= 16 tiles per walker): VGG-16's conv1_2 at batch 24
+    and conv2_1 (two channel slices) at batch 48; codes == slfp_encode_f32(float32 output), with and without the ReLU."""
+    from cnns_slfp_quantization_amd.layer_specs import ConvSpec
+    gen = torch.Generator(device=dev).manual_seed(2025)
+    for ci, co, h, n in ((64, 64, 224, 24), (64, 128, 112, 48)):
+        s = ConvSpec(c_in=ci, c_out=co, k=(3, 3), stride=(1, 1), pad=(1, 1), groups=1, bias=False, h=h, w=h, h_out=h, w_out=h, Ka=0.37, Kw=0.021)
+        for relu in (True, False):
+            lay = _Layer(lib, s, n, 8, dev, gen, post=True, relu=relu)
+            assert lay.kernel.startswith("dense_mfma"), lay.kernel
+            x = _synthetic_input(s, n, dev, gen, signed=not relu)
+            y_ref = lay.fwd_f32(lib, x)
+            codes_ref = _encode(lib, y_ref, 0.2345, lib.FMT_ACT8)
+            del y_ref
+            xc = _encode(lib, x, s.Ka, lib.FMT_ACT8)
+            for src, is_codes in ((x, False), (xc, True)):
+                yc = lay.fwd_codes(lib, src, is_codes, 0.2345, 8)
+                bad = int((yc != codes_ref).sum())
+                assert bad == 0, (ci, co, h, n, relu, is_codes, bad, yc.numel())
+                del yc
+
+
 @pytest.mark.parametrize("qbits", [8, 7])
 def test_small_k_stem_writes_the_next_layers_codes(lib, dev, qbits):
     """VGG-16's first layer (3x3 s1 3 -> 64 on the one-k-step MFMA stem, nets_cifar/vgg16.py:31): float32 image in, the
