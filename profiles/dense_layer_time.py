@@ -8,7 +8,8 @@ from cnns_slfp_quantization_amd import _lib as lib
 
 L = lib.load()
 dev = torch.device("cuda:0")
-LAYERS = [(64, 64, 224, 128), (64, 128, 112, 128), (64, 64, 56, 128), (16, 64, 55, 256), (64, 256, 13, 256)]
+LAYERS = [(64, 64, 224, 128), (64, 128, 112, 128), (64, 64, 56, 128), (16, 64, 55, 256), (64, 256, 13, 256)][:int(os.environ.get("DLT_LAYERS", "5"))]
+VARIANTS = (("resident", None), ("per_tile", "1"), ("resident2", None))[:int(os.environ.get("DLT_VARIANTS", "3"))]   # ablation runs (profiles/ablate_dense_res.sh): 1
 for ci, co, h, n in LAYERS:
     d = lib.ConvDesc(n=n, c_in=ci, h=h, w=h, c_out=co, kh=3, kw=3, stride_h=1, stride_w=1, pad_h=1, pad_w=1, dil_h=1, dil_w=1, groups=1,
                      x_layout=lib.LAYOUT_NHWC, y_layout=lib.LAYOUT_NHWC, qbits=8, ka=0.2, kw_scale=0.03, mfma_passes=1, reserved=0)
@@ -20,7 +21,7 @@ for ci, co, h, n in LAYERS:
     y = torch.empty((n, h, h, co), device=dev)
     yc = torch.empty((n, h, h, co), dtype=torch.uint8, device=dev)
     res = {}
-    for tag, env in (("resident", None), ("per_tile", "1"), ("resident2", None)):
+    for tag, env in VARIANTS:
         os.environ.pop("SLFP_DENSE_NORES", None)
         if env:
             os.environ["SLFP_DENSE_NORES"] = env

@@ -227,10 +227,10 @@ def test_dense_layers_on_codes_are_bit_identical_to_the_float32_interface(lib, d
     assert L.slfp_conv2d_codes_supported(ctypes.byref(d), ctypes.byref(io), 0, 1) == 1
 
 
-def test_resident_weight_dense_kernel_with_alternating_wave_groups_writes_the_same_codes(lib, dev):
-    """k_dense3x3_res<DEPHASE>: on long walks with code output the second wave of every SIMD runs the previous tile's epilogue
-    before its MFMAs (csrc/conv_dense.hip).  Sizes past the switch-over (>= 16 tiles per walker): VGG-16's conv1_2 at batch 24
-    and conv2_1 (two channel slices) at batch 48; codes == slfp_encode_f32(float32 output), with and without the ReLU."""
+def test_resident_weight_dense_kernel_writes_the_same_codes_on_long_walks(lib, dev):
+    """k_dense3x3_res with code output where every persistent workgroup walks over many tiles (>= 16 per walker; the small
+    cases of the test above give each walker one): VGG-16's conv1_2 at batch 24 and conv2_1 (two channel slices) at batch 48;
+    codes == slfp_encode_f32(float32 output), float32 and code input, with and without the ReLU."""
     from cnns_slfp_quantization_amd.layer_specs import ConvSpec
     gen = torch.Generator(device=dev).manual_seed(2025)
     for ci, co, h, n in ((64, 64, 224, 24), (64, 128, 112, 48)):
