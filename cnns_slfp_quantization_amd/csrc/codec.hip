@@ -77,6 +77,7 @@ static Switches read_switches() {
     e = std::getenv("SLFP_DENSE_NWB");
     w.dense_nwb = e ? atoi(e) : 0;
     w.dense_res = std::getenv("SLFP_DENSE_NORES") == nullptr;
+    w.dense_encx = std::getenv("SLFP_DENSE_NOENCX") == nullptr;
     w.stem_im2row = std::getenv("SLFP_STEM_IM2ROW") != nullptr;
     e = std::getenv("SLFP_PW_STREAM_MAX_KB");
     w.pw_stream_max_kb = e ? atoi(e) : 30;   // round 3 (profiles/ab_env_long.sh): W above 30 KiB runs on the tiled kernel -- MobileNetV1 +0.3-0.4 % (128->128, 128->256, 256->256), ShuffleNetV2 14.8 -> 17.5 k images/s (its 116- / 232-channel layers), ResNet-50 / SqueezeNet unchanged

@@ -62,6 +62,9 @@ struct DenseParams {
     int y_sgn;            // no ReLU in front of the output quantizer: codes carry a sign
     int y_fmt;            // kFmtAct8 | kFmtSfp7
     EncArgs enc_out;      // kEncCode table of (y_ka, y_fmt); filled into LDS after the main loop
+    // k_dense3x3_res<ENCX>: the float32 input itself (C_in == 64) is encoded where the halo is staged -- no pre-pass, no fp16 copy
+    const float* x32;
+    EncArgsCompact enc_in;   // kEncF16P table of (Ka, fmt_act)
 };
 
 __device__ __forceinline__ uint32_t dn_x_off(int row, int chunk16) {
@@ -151,15 +154,33 @@ __global__ __launch_bounds__(256) void k_dense_decode(const uint8_t* __restrict_
     *reinterpret_cast<half8*>(xe + idx * 8) = h;
 }
 
-// Epilogue of both GEMM kernels: Conv2d_Q's (acc * Ka) * Kw with the reference's two roundings, the fused post-op, and either
-// float32 stores (16 bytes per lane: 4 consecutive channels of one pixel) or the consumer's 1-byte codes.  Code output: the 4
-// channel tiles of a wave are encoded, transposed across the lane quarters (rows_transpose4) so that a lane holds 16
-// CONSECUTIVE channels of its pixel, and stored as one 16-byte piece.
+// The per-channel constants of a lane's four channel tiles: quantized-domain bias and the post-op's scale / shift.  The
+// persistent kernel loads them ONCE (inside its tile loop every one of these loads was followed by s_waitcnt vmcnt(0), which
+// on gfx9 also waits for the tile's stores so far: four exposed round trips per tile).
+struct EpiConsts { float4 bq[4]; PostVec pv[4]; };
+__device__ __forceinline__ void dense_epilogue_consts(const DenseParams& p, int wn, int nt0, int kq, EpiConsts& k) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ch = (nt0 + wn * 4 + j) * 16 + kq * 4;
+        k.bq[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        k.pv[j].sc = make_float4(1.f, 1.f, 1.f, 1.f);
+        k.pv[j].sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ch < p.O) {
+            if (p.bias) {
+                const float4 bb = *reinterpret_cast<const float4*>(p.bias + ch);
+                k.bq[j] = make_float4(256.f * ((bb.x / p.s1) / p.s2), 256.f * ((bb.y / p.s1) / p.s2),
+                                      256.f * ((bb.z / p.s1) / p.s2), 256.f * ((bb.w / p.s1) / p.s2));
+            }
+            k.pv[j] = post_load(p.post, ch);
+        }
+    }
+}
+
 // TAB_READY: the code table already sits at `smem` (k_dense3x3_res keeps it next to its operand tiles); otherwise it is filled
 // over the dead operand tiles here.
 template <int MT, bool TAB_READY = false>
-__device__ __forceinline__ void dense_epilogue(const DenseParams& p, const floatx4 (&acc)[MT][4], unsigned char* smem, int n, int th,
-                                               int tw, int TH, int wm, int wn, int nt0, int col, int kq) {
+__device__ __forceinline__ void dense_epilogue_apply(const DenseParams& p, const floatx4 (&acc)[MT][4], unsigned char* smem, int n, int th,
+                                                     int tw, int TH, int wm, int wn, int nt0, int col, int kq, const EpiConsts& k) {
     const int gow = tw * kDnTW + col;
     if (p.yc) {
         if constexpr (!TAB_READY) {
@@ -169,25 +190,8 @@ __device__ __forceinline__ void dense_epilogue(const DenseParams& p, const float
         }
         const float r1 = p.enc_out.r1, lo = p.enc_out.lo, hi = p.enc_out.hi;
         const int chw = (nt0 + wn * 4) * 16;   // this wave's 64 channels
-        float4 bq[4];
-        PostVec pv[4];
         PostOp po = p.post;
         po.relu = 0;   // the ReLU is folded into the quantizer (enc4_code_relu)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int ch = chw + j * 16 + kq * 4;
-            bq[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            pv[j].sc = make_float4(1.f, 1.f, 1.f, 1.f);
-            pv[j].sh = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ch < p.O) {
-                if (p.bias) {
-                    const float4 bb = *reinterpret_cast<const float4*>(p.bias + ch);
-                    bq[j] = make_float4(256.f * ((bb.x / p.s1) / p.s2), 256.f * ((bb.y / p.s1) / p.s2),
-                                        256.f * ((bb.z / p.s1) / p.s2), 256.f * ((bb.w / p.s1) / p.s2));
-                }
-                pv[j] = post_load(p.post, ch);
-            }
-        }
         const int chs = chw + kq * 16;   // after the transpose: this lane's 16 channels
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
@@ -196,11 +200,11 @@ __device__ __forceinline__ void dense_epilogue(const DenseParams& p, const float
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float4 r;
-                r.x = ((acc[i][j][0] + bq[j].x) * p.s1x) * p.s2;
-                r.y = ((acc[i][j][1] + bq[j].y) * p.s1x) * p.s2;
-                r.z = ((acc[i][j][2] + bq[j].z) * p.s1x) * p.s2;
-                r.w = ((acc[i][j][3] + bq[j].w) * p.s1x) * p.s2;
-                r = post_apply_v(r, po, pv[j]);
+                r.x = ((acc[i][j][0] + k.bq[j].x) * p.s1x) * p.s2;
+                r.y = ((acc[i][j][1] + k.bq[j].y) * p.s1x) * p.s2;
+                r.z = ((acc[i][j][2] + k.bq[j].z) * p.s1x) * p.s2;
+                r.w = ((acc[i][j][3] + k.bq[j].w) * p.s1x) * p.s2;
+                r = post_apply_v(r, po, k.pv[j]);
                 if (p.y_sgn) c[j] = code_sign4(enc4_code<false>(r, r1, lo, hi, smem), r, p.y_fmt);
                 else c[j] = enc4_code_relu(r, r1, lo, hi, smem);
             }
@@ -216,25 +220,30 @@ __device__ __forceinline__ void dense_epilogue(const DenseParams& p, const float
     for (int j = 0; j < 4; ++j) {
         const int ch = (nt0 + wn * 4 + j) * 16 + kq * 4;
         if (ch >= p.O) continue;
-        float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.bias) {
-            const float4 bb = *reinterpret_cast<const float4*>(p.bias + ch);
-            bq = make_float4(256.f * ((bb.x / p.s1) / p.s2), 256.f * ((bb.y / p.s1) / p.s2),
-                             256.f * ((bb.z / p.s1) / p.s2), 256.f * ((bb.w / p.s1) / p.s2));
-        }
-        const PostVec pv = post_load(p.post, ch);
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int goh = th * TH + wm * MT + i;
             if (goh >= p.Ho || gow >= p.Wo) continue;
             float4 r;
-            r.x = ((acc[i][j][0] + bq.x) * p.s1x) * p.s2;
-            r.y = ((acc[i][j][1] + bq.y) * p.s1x) * p.s2;
-            r.z = ((acc[i][j][2] + bq.z) * p.s1x) * p.s2;
-            r.w = ((acc[i][j][3] + bq.w) * p.s1x) * p.s2;
-            st_stream4<SLFP_NT_DENSE>(p.y + (((size_t)n * p.Ho + goh) * p.Wo + gow) * p.O + ch, post_apply_v(r, p.post, pv));
+            r.x = ((acc[i][j][0] + k.bq[j].x) * p.s1x) * p.s2;
+            r.y = ((acc[i][j][1] + k.bq[j].y) * p.s1x) * p.s2;
+            r.z = ((acc[i][j][2] + k.bq[j].z) * p.s1x) * p.s2;
+            r.w = ((acc[i][j][3] + k.bq[j].w) * p.s1x) * p.s2;
+            st_stream4<SLFP_NT_DENSE>(p.y + (((size_t)n * p.Ho + goh) * p.Wo + gow) * p.O + ch, post_apply_v(r, p.post, k.pv[j]));
         }
     }
+}
+
+// Epilogue of the per-tile GEMM kernels: Conv2d_Q's (acc * Ka) * Kw with the reference's two roundings, the fused post-op, and either
+// float32 stores (16 bytes per lane: 4 consecutive channels of one pixel) or the consumer's 1-byte codes.  Code output: the 4
+// channel tiles of a wave are encoded, transposed across the lane quarters (rows_transpose4) so that a lane holds 16
+// CONSECUTIVE channels of its pixel, and stored as one 16-byte piece.
+template <int MT>
+__device__ __forceinline__ void dense_epilogue(const DenseParams& p, const floatx4 (&acc)[MT][4], unsigned char* smem, int n, int th,
+                                               int tw, int TH, int wm, int wn, int nt0, int col, int kq) {
+    EpiConsts k;
+    dense_epilogue_consts(p, wn, nt0, kq, k);
+    dense_epilogue_apply<MT, false>(p, acc, smem, n, th, tw, TH, wm, wn, nt0, col, kq, k);
 }
 
 // WM x WN = 8 waves; MT = output rows per wave.  Both operands arrive by LDS-DMA: no VALU work
@@ -585,7 +594,12 @@ __global__ __launch_bounds__(kDnThreads, (MT == 4 ? 2 : 4)) void k_dense3x3(cons
 // halo comes before them in the instruction stream.  Same fragment layout, same MFMA order: bit-identical to k_dense3x3.
 //   workgroup = 8 waves x MT rows x 16 columns x 64 output channels; LDS = 72 KiB W + 2 halos + the code table.
 // ======================================================================================
-template <int MT, int NSLOT>
+// ENCX (float32 interface, C_in == 64, one channel slice): the halo is loaded as float32 straight from the layer's input,
+// encoded with the threshold table (enc4_f16: the values k_dense_encode writes, bit for bit) and written to the same swizzled
+// LDS tile -- the loads of the NEXT tile are issued before the MFMAs of the current one and consumed behind them.  Saves the
+// pre-pass (64 -> 64 @224 at batch 128: 1.64 GB read + 0.82 GB written + 1.04 GB read back, 427 us) for ~50 VALU
+// instructions per 16-byte chunk.
+template <int MT, int NSLOT, bool ENCX>
 __global__ __launch_bounds__(kDnThreads, 2) void k_dense3x3_res(const DenseParams p) {
     constexpr int TH = 8 * MT, WT = 64 * 128;
     constexpr int IW = kDnTW + 2, IH = TH + 2, NPIX = IH * IW, PIECES = (NPIX + 7) / 8;
@@ -595,6 +609,9 @@ __global__ __launch_bounds__(kDnThreads, 2) void k_dense3x3_res(const DenseParam
     unsigned char* wres = smem;                 // [9 taps][WT]
     unsigned char* xsb = smem + 9 * WT;         // [2][PIECES KiB]
     unsigned char* tab = xsb + 2 * xbytes;      // code table of the consumer (kEncEntries * 8 bytes)
+    constexpr int kTabBytes = (kEncEntries * 8 + 63) & ~63;
+    unsigned char* tabx = tab + kTabBytes;      // ENCX: kEncF16P table of this layer's (Ka, format)
+    constexpr int XSL = (NPIX * 8 + kDnThreads - 1) / kDnThreads;   // ENCX: 16-byte chunks of a halo per thread
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 15, kq = lane >> 4;
@@ -642,6 +659,54 @@ __global__ __launch_bounds__(kDnThreads, 2) void k_dense3x3_res(const DenseParam
         }
     };
 
+    // ENCX: chunk task q = pixel * 8 + chunk c (channels {4j..4j+3, 16+4j..16+4j+3} + 32 g, c = 4 g + j) -> thread q % 512
+    uint32_t xslot[ENCX ? XSL : 1];
+    if constexpr (ENCX) {
+#pragma unroll
+        for (int j = 0; j < XSL; ++j) {
+            const int q = (int)threadIdx.x + kDnThreads * j;
+            const int pix = q >> 3, c = q & 7;
+            const int ih = pix / IW, iw = pix - ih * IW;
+            xslot[j] = pix < NPIX ? (uint32_t)(ih << 16 | iw << 8 | c) : 0xFFFFFFFFu;
+        }
+    }
+    float4 xa[ENCX ? XSL : 1], xb4[ENCX ? XSL : 1];
+    uint32_t xlive = 0;   // bit j: slot j of the tile in flight is a pixel of the image (else padding: encodes as +0)
+    // Every slot ALWAYS loads (padding slots from the start of the input, discarded when the tile is encoded): a load under a
+    // divergent `if` is waited for at the end of its block (hipcc: six serialized round trips per tile, measured +3.8 us).
+    auto load_tile = [&](uint32_t t) {   // float32 halo of tile t -> registers
+        const int tw = (int)(t % (uint32_t)p.tiles_w);
+        const uint32_t t2 = t / (uint32_t)p.tiles_w;
+        const int th = (int)(t2 % (uint32_t)p.tiles_h);
+        const int n = (int)(t2 / (uint32_t)p.tiles_h);
+        const int h0 = th * TH - p.ph, w0 = tw * kDnTW - p.pw;
+        const float* xn = p.x32 + (size_t)n * p.H * p.W * 64;
+        xlive = 0;
+#pragma unroll
+        for (int j = 0; j < XSL; ++j) {
+            const int gh = h0 + (int)(xslot[j] >> 16), gw = w0 + (int)((xslot[j] >> 8) & 0xFF);
+            const int c = (int)(xslot[j] & 7);
+            const bool inb = xslot[j] != 0xFFFFFFFFu && (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W;
+            const uint32_t off = inb ? (uint32_t)(gh * p.W + gw) * 64u + (uint32_t)((c >> 2) * 32 + (c & 3) * 4) : 0u;
+            xlive |= inb ? (1u << j) : 0u;
+            xa[j] = ld_stream4<SLFP_NT_DENSE>(xn + off);
+            xb4[j] = ld_stream4<SLFP_NT_DENSE>(xn + off + 16);
+        }
+    };
+    auto encode_tile = [&](int buf) {    // registers -> encoded, swizzled LDS tile (padding pixels: +0, as the zero page gave)
+        const float r1 = p.enc_in.r1, lo = p.enc_in.lo, hi = p.enc_in.hi;
+#pragma unroll
+        for (int j = 0; j < XSL; ++j) {
+            const int q = (int)threadIdx.x + kDnThreads * j;
+            const bool live = (xlive >> j) & 1u;
+            const uint2 e0 = enc4_f16(xa[j], r1, lo, hi, tabx);
+            const uint2 e1 = enc4_f16(xb4[j], r1, lo, hi, tabx);
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 v = live ? u32x4{e0.x, e0.y, e1.x, e1.y} : u32x4{0u, 0u, 0u, 0u};
+            if (q < NPIX * 8) *reinterpret_cast<u32x4*>(xsb + (size_t)buf * xbytes + dn_x_off(q >> 3, q & 7)) = v;
+        }
+    };
+
     // ---- all nine tap tiles of this channel slice: 72 pieces of 1 KiB, 9 per wave
     const int nt0 = nb * 4;
     {
@@ -656,7 +721,14 @@ __global__ __launch_bounds__(kDnThreads, 2) void k_dense3x3_res(const DenseParam
                    wres + (size_t)pq * 1024);
         }
     }
-    stage_tile(tile, 0);
+    if constexpr (ENCX) {
+        enc_fill_compact<kDnThreads>(reinterpret_cast<uint2*>(tabx), p.enc_in);
+        load_tile(tile);
+        __syncthreads();   // the table
+        encode_tile(0);
+    } else {
+        stage_tile(tile, 0);
+    }
     if (p.yc) enc_fill<kDnThreads>(reinterpret_cast<uint2*>(tab), p.enc_out);
 
     uint32_t xo[MT + 2][3];
@@ -666,6 +738,8 @@ __global__ __launch_bounds__(kDnThreads, 2) void k_dense3x3_res(const DenseParam
         for (int kw = 0; kw < 3; ++kw) xo[r][kw] = dn_x_off((wave * MT + r) * IW + col + kw, kq);
     const uint32_t wlane = (uint32_t)lane * 16u;
 
+    EpiConsts epi;
+    dense_epilogue_consts(p, 0, nt0, kq, epi);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -674,8 +748,11 @@ __global__ __launch_bounds__(kDnThreads, 2) void k_dense3x3_res(const DenseParam
         const uint32_t next = tile + t_step;
         const bool has_next = next < r_end;
 #ifndef SLFP_RES_NODMA
-        if (has_next) stage_tile(next, xb ^ 1);   // every wave left that buffer before the last barrier
+        // (every wave left that buffer before the last barrier)
+        if constexpr (ENCX) load_tile(has_next ? next : tile);   // unconditional: under `if (has_next)` the registers become loop phis, copied -- and waited for -- right here
+        else if (has_next) stage_tile(next, xb ^ 1);
 #endif
+        if constexpr (ENCX) __builtin_amdgcn_sched_barrier(0);   // the loads fly under the MFMAs: their encode stays behind them
         floatx4 acc[MT][4];
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -723,7 +800,12 @@ __global__ __launch_bounds__(kDnThreads, 2) void k_dense3x3_res(const DenseParam
                     }
         }
         // the next halo has had the whole tile to land; the stores of the previous tile are older still
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (ENCX) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (has_next) encode_tile(xb ^ 1);
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __syncthreads();
         {
             const int tw = (int)(tile % (uint32_t)p.tiles_w);
@@ -733,7 +815,7 @@ __global__ __launch_bounds__(kDnThreads, 2) void k_dense3x3_res(const DenseParam
 #ifdef SLFP_RES_NOST
             if (acc[0][0][0] == 12345.678f)   // never true for these inputs: the epilogue and its stores are skipped
 #endif
-            dense_epilogue<MT, true>(p, acc, tab, n, th, tw, TH, wave, 0, nt0, col, kq);
+            dense_epilogue_apply<MT, true>(p, acc, tab, n, th, tw, TH, wave, 0, nt0, col, kq, epi);
         }
         if (!has_next) break;
         tile = next;
@@ -858,14 +940,15 @@ static bool dense_res_applicable(const slfp_conv2d_desc& d, int planes, int cp) 
 template <int MT, int NSLOT>
 static int launch_dense_res_t(DenseParams& p, hipStream_t stream) {
     constexpr int TH = 8 * MT, PIECES = ((TH + 2) * (kDnTW + 2) + 7) / 8;
-    const size_t lds = 9 * 8192 + 2 * (size_t)PIECES * 1024 + ((kEncEntries * 8 + 63) & ~63);
+    const size_t lds = 9 * 8192 + 2 * (size_t)PIECES * 1024 + 2 * ((kEncEntries * 8 + 63) & ~63);
     p.tiles_h = (int)ceil_div(p.Ho, TH);
     p.n_blocks = (int)ceil_div((int64_t)p.O, 64);
     const int64_t T = (int64_t)p.N * p.tiles_h * p.tiles_w;
     if (T > 0x7FFFFFFF) return fail(SLFP_ERR_UNSUPPORTED, "dense MFMA conv: grid too large");
     int64_t gs = std::min<int64_t>(T, std::max<int64_t>(1, device_cu_count() / p.n_blocks));   // one workgroup per CU (LDS)
     if (gs >= 8) gs -= gs % 8;
-    auto fn = k_dense3x3_res<MT, NSLOT>;
+    auto fn = k_dense3x3_res<MT, NSLOT, false>;
+    if (p.x32) fn = k_dense3x3_res<MT, NSLOT, true>;
     const int rc = raise_lds_limit(reinterpret_cast<const void*>(fn), 160 * 1024);
     if (rc != SLFP_OK) return rc;
     p.nblocks = (uint32_t)(gs * p.n_blocks);
@@ -903,6 +986,10 @@ int launch_dense_mfma_io(const slfp_conv2d_desc& d, const ConvPlan& plan, const 
     const int planes = dense_planes(d, plan.passes);
     if (!dense_choose(d, planes, plan.h_out, plan.w_out, &g)) return fail(SLFP_ERR_UNSUPPORTED, "dense MFMA conv: no tiling fits");
     if (!workspace) return fail(SLFP_ERR_BAD_ARG, "dense MFMA conv: workspace required (slfp_conv2d_workspace_bytes)");
+    // k_dense3x3_res<ENCX>: float32 input of exactly one 64-channel chunk, one channel slice -> encoded where the halo is staged
+    const EncArgs* tx = nullptr;
+    if (!io.x_codes && planes == 1 && d.c_in == 64 && d.c_out <= 64 && switches().dense_encx && dense_res_applicable(d, planes, (int)dense_cp(d)))
+        tx = act_table(d.ka, plan.fmt_act, kEncF16P);
     // ---- pass 1: encode the input once (every element is reused KH*KW * C_out times by pass 2)
     unsigned char* zero_page = reinterpret_cast<unsigned char*>(workspace);
     _Float16* xe = reinterpret_cast<_Float16*>(zero_page + 256);
@@ -911,7 +998,9 @@ int launch_dense_mfma_io(const slfp_conv2d_desc& d, const ConvPlan& plan, const 
     const int64_t n_chunks16 = d.n * d.h * d.w * (cp / 8);
     const ScaleDiv sd = make_scale_div(d.ka, 4);
     const unsigned egrid = (unsigned)ceil_div(n_chunks16, 256);
-    if (io.x_codes) {
+    if (tx) {
+        // no pre-pass
+    } else if (io.x_codes) {
         const uint8_t* xc = reinterpret_cast<const uint8_t*>(x_any);
         if (plan.fmt_act == kFmtAct8)
             hipLaunchKernelGGL((k_dense_decode<kFmtAct8>), dim3(egrid), dim3(256), 0, stream, xc, xe, xlo, zero_page, n_chunks16, (int)d.c_in, cp);
@@ -928,6 +1017,8 @@ int launch_dense_mfma_io(const slfp_conv2d_desc& d, const ConvPlan& plan, const 
     p.xe = xe; p.xlo = xlo; p.zero_page = zero_page;
     p.w = reinterpret_cast<const _Float16*>(wblob); p.bias = bias; p.y = y; p.post = post;
     p.yc = nullptr; p.y_sgn = 0; p.y_fmt = kFmtAct8; p.enc_out.valid = 0;
+    p.x32 = nullptr; p.enc_in.valid = 0;
+    if (tx) { p.x32 = x; p.enc_in = enc_compact(*tx); }
     if (io.y_codes) {
         const EncArgs* t = enc_table(io.y_ka, io.y_fmt, kEncCode);
         if (!t->valid) return fail(SLFP_ERR_UNSUPPORTED, "dense MFMA conv: no code table for the consumer's scale");

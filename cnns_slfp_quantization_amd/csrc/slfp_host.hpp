@@ -57,6 +57,7 @@ struct Switches {
     bool dense_generic;       // SLFP_DENSE_GENERIC: 3x3 stride-1 layers on the general k_dense_mfma instead of the unrolled k_dense3x3
     int dense_cfg;            // SLFP_DENSE_CFG=<wm><wn><mt> (e.g. 244): force a dense k x k tiling where it fits (sweeps); 0 = cost model
     int dense_nwb;            // SLFP_DENSE_NWB=2: keep two weight buffers everywhere (A/B of the three-buffer pipeline)
+    bool dense_encx;          // SLFP_DENSE_NOENCX unsets it: k_dense3x3_res encodes the float32 halo on load (C_in == 64, C_out <= 64) instead of reading the pre-pass's fp16 copy
     bool dense_res;           // SLFP_DENSE_NORES unsets it: 3x3 stride-1 layers with C_in <= 64 on the persistent weights-resident k_dense3x3_res
     bool stem_im2row;         // SLFP_STEM_IM2ROW: large-kernel stems through the im2row workspace (the round-1 form; A/B of k_stem_rows)
     int pw_stream_max_kb;     // SLFP_PW_STREAM_MAX_KB: largest W (KiB, fp16) the float32-interface path gives to the LDS-resident stream kernel (default 30; its capacity is 128)

@@ -9,7 +9,7 @@ from cnns_slfp_quantization_amd import _lib as lib
 L = lib.load()
 dev = torch.device("cuda:0")
 LAYERS = [(64, 64, 224, 128), (64, 128, 112, 128), (64, 64, 56, 128), (16, 64, 55, 256), (64, 256, 13, 256)][:int(os.environ.get("DLT_LAYERS", "5"))]
-VARIANTS = (("resident", None), ("per_tile", "1"), ("resident2", None))[:int(os.environ.get("DLT_VARIANTS", "3"))]   # ablation runs (profiles/ablate_dense_res.sh): 1
+VARIANTS = (("resident", None), ("per_tile", "SLFP_DENSE_NORES"), ("fp16_copy", "SLFP_DENSE_NOENCX"), ("resident2", None))[:int(os.environ.get("DLT_VARIANTS", "4"))]   # ablation runs (profiles/ablate_dense_res.sh): 1
 for ci, co, h, n in LAYERS:
     d = lib.ConvDesc(n=n, c_in=ci, h=h, w=h, c_out=co, kh=3, kw=3, stride_h=1, stride_w=1, pad_h=1, pad_w=1, dil_h=1, dil_w=1, groups=1,
                      x_layout=lib.LAYOUT_NHWC, y_layout=lib.LAYOUT_NHWC, qbits=8, ka=0.2, kw_scale=0.03, mfma_passes=1, reserved=0)
@@ -23,8 +23,9 @@ for ci, co, h, n in LAYERS:
     res = {}
     for tag, env in VARIANTS:
         os.environ.pop("SLFP_DENSE_NORES", None)
+        os.environ.pop("SLFP_DENSE_NOENCX", None)
         if env:
-            os.environ["SLFP_DENSE_NORES"] = env
+            os.environ[env] = "1"
         L.slfp_debug_reload_switches()
         for codes in (False, True):
             io = lib.ConvIo(x_codes=0, y_codes=1 if codes else 0, y_ka=0.3, y_qbits=8)
@@ -45,6 +46,7 @@ for ci, co, h, n in LAYERS:
             e1.record(); torch.cuda.synchronize()
             res[(tag, codes)] = e0.elapsed_time(e1) / 20 * 1e3
     os.environ.pop("SLFP_DENSE_NORES", None)
+    os.environ.pop("SLFP_DENSE_NOENCX", None)
     L.slfp_debug_reload_switches()
     gmac = n * h * h * ci * co * 9 / 1e9
     print(f"{ci}->{co} @{h} batch {n} ({gmac:.0f} GMAC): " + "  ".join(f"{t}{'/codes' if c else '/f32'} {v:.0f} us" for (t, c), v in res.items()), flush=True)

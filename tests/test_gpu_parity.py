@@ -1495,24 +1495,27 @@ def test_resident_weight_dense_kernel_is_bit_identical_to_the_per_tile_form(lib,
         cases = (  # c_in, c_out, n, h, w, pad, bias, qbits
             (64, 64, 2, 224, 224, 1, False, 8), (64, 128, 3, 112, 112, 1, True, 8), (64, 64, 40, 56, 56, 1, False, 8),
             (48, 192, 3, 27, 27, 1, True, 7), (16, 64, 2, 55, 55, 1, False, 7), (64, 72, 2, 13, 29, 1, False, 8),
-            (32, 256, 1, 19, 17, 0, True, 8), (64, 64, 1, 5, 5, 1, False, 8))
+            (32, 256, 1, 19, 17, 0, True, 8), (64, 64, 1, 5, 5, 1, False, 8), (64, 48, 3, 37, 21, 1, True, 7), (64, 64, 2, 30, 30, 0, True, 8))
         for ci, co, n, h, w, pad, bias, qbits in cases:
             x = torch.relu(torch.randn((n, h, w, ci), generator=gen, device=dev)) * (5.0 * Ka)
             x.view(-1)[13::1009] = float("nan")
             wt = torch.randn((co, ci, 3, 3), generator=gen, device=dev) * (4.0 * Kw)
             b = (torch.randn(co, generator=gen, device=dev) * 0.3) if bias else None
             outs = []
-            for old in (False, True):
+            for env in (None, "SLFP_DENSE_NOENCX", "SLFP_DENSE_NORES"):   # encode-on-load where it applies / fp16 copy / per-tile kernel
                 os.environ.pop("SLFP_DENSE_NORES", None)
-                if old:
-                    os.environ["SLFP_DENSE_NORES"] = "1"
+                os.environ.pop("SLFP_DENSE_NOENCX", None)
+                if env:
+                    os.environ[env] = "1"
                 L.slfp_debug_reload_switches()
                 y, kern = _raw_conv(lib, dev, x, wt, b, 1, pad, 1, Ka, Kw, qbits)
                 assert kern.startswith("dense_mfma"), kern
                 outs.append(y.cpu().numpy())
-            assert same_bits(outs[0], outs[1]), (ci, co, n, h, w, pad, bias, qbits)
+            assert same_bits(outs[1], outs[2]), (ci, co, n, h, w, pad, bias, qbits)
+            assert same_bits(outs[0], outs[1]), (ci, co, n, h, w, pad, bias, qbits, "encode on load")
             assert np.isnan(outs[0]).any()
         os.environ.pop("SLFP_DENSE_NORES", None)
+        os.environ.pop("SLFP_DENSE_NOENCX", None)
         L.slfp_debug_reload_switches()
         # against the oracle (clean input, two images of a ragged case)
         x = torch.relu(torch.randn((2, 21, 37, 64), generator=gen, device=dev)) * (5.0 * Ka)
@@ -1523,6 +1526,7 @@ def test_resident_weight_dense_kernel_is_bit_identical_to_the_per_tile_form(lib,
         assert np.abs(got - ref).max() <= _tol(kern) * np.abs(ref).max(), np.abs(got - ref).max() / np.abs(ref).max()
     finally:
         os.environ.pop("SLFP_DENSE_NORES", None)
+        os.environ.pop("SLFP_DENSE_NOENCX", None)
         L.slfp_debug_reload_switches()
 
 
