@@ -114,8 +114,8 @@ class Layer:
 FAMILY_KERNELS = {"dw3x3_nhwc": ("k_dw3x3",), "stem_nhwc": ("k_stem", "k_stem_fixed"), "direct_nhwc": ("k_direct",),
                   "pw_mfma_f16x1": ("k_pw_stream", "k_pw_tiled"), "pw_mfma_f16x3": ("k_pw_stream", "k_pw_tiled"),
                   "pw_mfma_f16_exact": ("k_pw_stream", "k_pw_tiled"),
-                  "dense_mfma_f16x1": ("k_dense_mfma", "k_dense3x3", "k_dense_encode"), "dense_mfma_f16x3": ("k_dense_mfma", "k_dense_encode"),
-                  "dense_mfma_f16_exact": ("k_dense_mfma", "k_dense3x3", "k_dense_encode"),
+                  "dense_mfma_f16x1": ("k_dense_mfma", "k_dense3x3", "k_dense3x3_res", "k_dense_encode"), "dense_mfma_f16x3": ("k_dense_mfma", "k_dense_encode"),
+                  "dense_mfma_f16_exact": ("k_dense_mfma", "k_dense3x3", "k_dense3x3_res", "k_dense_encode"),
                   "stem_mfma_f16x1": ("k_stem_mfma", "k_stem_im2row"), "stem_mfma_f16_exact": ("k_stem_mfma", "k_stem_im2row"),
                   "stem_small_mfma_f16x1": ("k_stem_small",), "stem_small_mfma_f16_exact": ("k_stem_small",),
                   # the code path (run_codes_config): families of slfp_conv2d_fwd_codes
